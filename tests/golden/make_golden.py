@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.json from the REAL reference.
+
+Runs only in the dev container: it needs oracle/_ref/librspt_ref.so, which
+oracle/Makefile compiles from the reference's own sources under /root/reference
+(nothing of the reference is copied into this repo).  The fixtures are data:
+input descriptions (tests/cases.py builds the bytes deterministically) and the
+reference's outputs -- sizes, hashes, final nb, PRDN, and the full stream for
+small cases.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import struct
+import sys
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases  # noqa: E402
+from oracle.oracle import Oracle, Ref  # noqa: E402
+
+FULL_LIMIT = 600  # bytes; longer streams are pinned by size + two hashes
+
+
+def chunk_count(stream, hdr):
+    """number of [u32 len][hzr stream] chunks = the packer's final nb."""
+    pos, k = 1 + hdr, 0
+    while pos < len(stream):
+        (ln,) = struct.unpack_from("<I", stream, pos)
+        pos += 4 + ln
+        k += 1
+    assert pos == len(stream)
+    return k
+
+
+def main():
+    ref, orc = Ref(), Oracle()
+    out = {"generator": "tests/golden/make_golden.py (oracle/_ref = reference compiled from /root/reference)", "hzr": {}, "packers": {}}
+    for name, data in cases.hzr_kat_inputs().items():
+        s = ref.hzr_encode(data)
+        assert ref.hzr_decode(s, data.size) == data.tobytes()
+        ok, n = ref.hzr_verify(s)
+        assert ok and n == data.size
+        e = {"in_size": int(data.size), "in_crc32": zlib.crc32(data.tobytes()), "size": len(s), "fnv1a": orc.fnv1a(s), "crc32": zlib.crc32(s)}
+        if len(s) <= FULL_LIMIT:
+            e["stream"] = s.hex()
+        out["hzr"][name] = e
+    for c in cases.packer_cases():
+        pk = ref.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+        s = pk.compress(c["data"])
+        dec, used, rc = pk.decompress(s)
+        assert used == len(s) and rc == 0, (c["name"], used, len(s))
+        hdr = 3 * c["nch"] if c["kind"] in ("dct", "hadamard") else 0
+        e = {
+            "kind": c["kind"], "bps": c["bps"], "nch": c["nch"], "ns": c["ns"], "nb": c["nb"],
+            "in_crc32": zlib.crc32(c["data"].tobytes()),
+            "size": len(s), "fnv1a": orc.fnv1a(s), "crc32": zlib.crc32(s),
+            "final_nb": chunk_count(s, hdr),
+            "decoded_crc32": zlib.crc32(dec),
+            "lossless": dec == c["data"].tobytes(),
+        }
+        if c["kind"] in ("dct", "hadamard"):
+            v = orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"])
+            e["prdn"] = None if v != v else v  # NaN (degenerate denominators) -> null
+        if c["store"] == "full" and len(s) <= FULL_LIMIT:
+            e["stream"] = s.hex()
+        out["packers"][c["name"]] = e
+        print("%-28s %-10s size %8d nb %d->%d fnv %08x %s" % (c["name"], c["kind"], len(s), c["nb"], e["final_nb"], e["fnv1a"], "prdn %s" % e["prdn"] if "prdn" in e else ""))
+        pk.close()
+    with open(os.path.join(HERE, "golden.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()

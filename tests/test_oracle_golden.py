@@ -1,0 +1,104 @@
+"""Pin the CPU restatement (oracle/rspt_oracle.c) against the committed golden
+fixtures, which were produced by the compiled reference (tests/golden/make_golden.py).
+Runs everywhere (no GPU, no /root/reference)."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import cases
+
+SLOW = {"ecg12x4096_dct"}  # ~2 s each of O(n^2) cosine sums: still run, listed for the record
+
+
+def test_crc32c_check_value(orc):
+    assert orc.crc32c(b"123456789") == 0xE3069283  # standard CRC-32C check (hzr_crc32c.c:77-97)
+    assert orc.crc32c(b"") == 0
+    assert orc.crc32c(b"\x00") == 0x527D5351  # the Fill(0) block CRC seen in every all-zero block
+
+
+def test_survey_kats(orc):
+    """Known answers quoted in SURVEY.md 8(c), independent of golden.json."""
+    enc = lambda b: orc.hzr_encode(np.frombuffer(b, dtype=np.uint8)).hex()
+    assert enc(bytes(100)) == "64000000" + "0000" + "51537d52" + "02" + "00"
+    assert enc(b"A" * 10) == "0a000000" + "0000" + "eecd6de1" + "02" + "41"
+    assert enc(b"abracadabra abracadabra") == "170000000e00ccc813820186e1184124a39c627ca27dca27da07"
+
+
+@pytest.mark.parametrize("name", sorted(cases.hzr_kat_inputs().keys()))
+def test_hzr_kat(orc, golden, name):
+    data = cases.hzr_kat_inputs()[name]
+    g = golden["hzr"][name]
+    assert zlib.crc32(data.tobytes()) == g["in_crc32"], "test input drifted"
+    s = orc.hzr_encode(data)
+    assert len(s) == g["size"]
+    assert orc.fnv1a(s) == g["fnv1a"] and zlib.crc32(s) == g["crc32"]
+    if "stream" in g:
+        assert s.hex() == g["stream"]
+    dec, used = orc.hzr_decode(s, data.size)
+    assert dec == data.tobytes() and used == len(s)
+    ok, n = orc.hzr_verify(s)
+    assert ok and n == data.size
+    assert len(s) <= orc.hzr_max_compressed_size(data.size)
+
+
+def _names():
+    return [c["name"] for c in cases.packer_cases()]
+
+
+@pytest.mark.parametrize("name", _names())
+def test_packer_golden(orc, golden, packer_cases, name):
+    c, g = packer_cases[name], golden["packers"][name]
+    assert zlib.crc32(c["data"].tobytes()) == g["in_crc32"], "test input drifted"
+    pk = orc.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    s = pk.compress(c["data"])
+    assert len(s) == g["size"]
+    assert orc.fnv1a(s) == g["fnv1a"] and zlib.crc32(s) == g["crc32"]
+    if "stream" in g:
+        assert s.hex() == g["stream"]
+    assert orc.packer_nb(pk) == g["final_nb"]
+    assert len(s) <= orc.packer_max_compressed_size(pk)
+    dec, used, rc = pk.decompress(s)
+    assert rc == 0 and used == len(s)
+    assert zlib.crc32(dec) == g["decoded_crc32"]
+    if g["lossless"]:
+        assert dec == c["data"].tobytes()
+    if g.get("prdn") is not None:
+        assert abs(orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"]) - g["prdn"]) < 1e-9
+    pk.close()
+
+
+def test_fast_verify_gives_same_stream_and_nb(orc, golden, packer_cases):
+    """The derived escalation criterion (SURVEY 8 note a-3) == round-trip check."""
+    for name, c in packer_cases.items():
+        if c["kind"] != "xdelta_hzr" or c["nch"] * c["ns"] > 500000:
+            continue
+        pk = orc.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+        orc.packer_set_fast_verify(pk, True)
+        s = pk.compress(c["data"])
+        assert orc.fnv1a(s) == golden["packers"][name]["fnv1a"], name
+        assert orc.packer_nb(pk) == golden["packers"][name]["final_nb"], name
+        pk.close()
+
+
+def test_nb_state_persists_across_calls(orc):
+    """nr_bytes_to_compress_ mutates on escalation and stays (xdelta_hzr.cpp:63-69)."""
+    big = cases._rand_native(2, 500, 4, 91, 1 << 20)
+    small = cases._rand_native(2, 500, 4, 92, 10)
+    pk = orc.packer("xdelta_hzr", 4, 2, 500, 1)
+    s_small_before = pk.compress(small)
+    nb_small = orc.xdelta_needed_nb(orc.xdelta_forward(orc.native_to_i32(small, 500, 2, 4)), 4, 1)
+    assert orc.packer_nb(pk) == nb_small
+    pk.compress(big)
+    nb = orc.packer_nb(pk)
+    v = orc.xdelta_forward(orc.native_to_i32(big, 500, 2, 4))
+    assert nb == orc.xdelta_needed_nb(v, 4, 1) and nb > nb_small
+    s_small_after = pk.compress(small)
+    assert orc.packer_nb(pk) == nb and len(s_small_after) > len(s_small_before)
+    # stream structure: method byte + nb chunks
+    pos, k = 1, 0
+    while pos < len(s_small_after):
+        pos += 4 + struct.unpack_from("<I", s_small_after, pos)[0]
+        k += 1
+    assert k == nb and pos == len(s_small_after)
