@@ -1,0 +1,141 @@
+/*
+ * rspt_hip.h -- C ABI of the MI355X (gfx950) signal_packer hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  The reference has no FFI of its own (it is a single C++ library);
+ * the entry points below are what its i_signal_packer factories and
+ * compress()/decompress() virtuals (lib_rspt/signal_packer.h:29-73) bind to
+ * when the path runs on the GPU -- include/signal_packer.h holds the
+ * API-identical C++ classes that call them, INTEGRATION.md shows the
+ * reference-side binding.
+ *
+ * Conventions: every function returns RSPT_HIP_OK (0) or a negative
+ * rspt_hip_status; nothing throws across this boundary.  A handle owns its
+ * device workspace and one HIP stream and is not thread-safe (one handle per
+ * host thread), exactly like a reference packer instance
+ * (signal_packer_base.h:20-21 scratch tensors).  There is no CPU fallback: if
+ * no gfx950 device is usable, create() fails.
+ */
+#ifndef RSPT_HIP_H_
+#define RSPT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rspt_hip_packer rspt_hip_packer;
+
+/* Factory selector -- NOT the stream's method byte (which is 0,0,1,2).
+ * Replaces i_signal_packer::new_hzr / new_xdelta_hzr / new_dct / new_hadamard
+ * (lib_rspt/signal_packer.h:59-69). */
+enum rspt_hip_kind {
+    RSPT_HIP_KIND_HZR = 0,        /* lib_signalpacker/signal_packer_hzr.cpp:34-68        */
+    RSPT_HIP_KIND_XDELTA_HZR = 1, /* lib_signalpacker/signal_packer_xdelta_hzr.cpp:34-88 */
+    RSPT_HIP_KIND_DCT = 2,        /* lib_signalpacker/signal_packer_dct.cpp:36-156       */
+    RSPT_HIP_KIND_HADAMARD = 3    /* lib_signalpacker/signal_packer_hadamard.cpp:35-107  */
+};
+
+enum rspt_hip_status {
+    RSPT_HIP_OK = 0,
+    RSPT_HIP_ERR_ARG = -1,         /* bad kind / sizes (bps not 1..4, nb not 1..4, ns not 2^k for hadamard ...) */
+    RSPT_HIP_ERR_NO_DEVICE = -2,   /* no usable gfx950 device; there is no CPU path */
+    RSPT_HIP_ERR_ALLOC = -3,       /* device or host allocation failed */
+    RSPT_HIP_ERR_LAUNCH = -4,      /* a HIP call or kernel launch failed (see rspt_hip_last_hip_error) */
+    RSPT_HIP_ERR_DST_TOO_SMALL = -5, /* compressed block does not fit dst_max_len / dst_stride */
+    RSPT_HIP_ERR_CORRUPT = -6,     /* decompress: malformed stream */
+    RSPT_HIP_ERR_UNSUPPORTED = -7  /* shape outside what the kernels handle (documented in DESIGN.md) */
+};
+
+const char* rspt_hip_status_string(int status);
+/* hipError_t of the last failing HIP call on this handle (0 if none). */
+int rspt_hip_last_hip_error(const rspt_hip_packer* p);
+
+/* Number of gfx950 devices visible to this process (0 if none). */
+int rspt_hip_device_count(void);
+
+/* Constructor.  Replaces the packer constructors
+ * (signal_packer_xdelta_hzr.cpp:42-50, _hzr.cpp:42-49, _hadamard.cpp:47-55,
+ * _dct.cpp:49-58): same meaning of (bytes_per_sample, nr_channels,
+ * nr_samples_per_channel, nr_bytes_to_encode); `nb` is read by
+ * RSPT_HIP_KIND_XDELTA_HZR only.  `device` is the HIP device ordinal. */
+int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t nch, size_t ns, size_t nb, int device);
+
+/* Replaces i_signal_packer::delete_* (signal_packer.h:60-72). */
+void rspt_hip_packer_destroy(rspt_hip_packer* p);
+
+/* i_signal_packer::compress (signal_packer.h:44), host buffers.
+ * src = bps*nch*ns bytes, interleaved sample-major little-endian.
+ * Fails with RSPT_HIP_ERR_DST_TOO_SMALL instead of the reference's undefined
+ * result when the stream does not fit dst_max_len. */
+int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, size_t dst_max_len, size_t* dst_len);
+
+/* i_signal_packer::decompress (signal_packer.h:57), host buffers.
+ * *src_len is an OUTPUT (bytes consumed), as in the reference. */
+int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_len, void* dst_host);
+
+/* Worst-case stream size of ONE block for this packer, allowing for nb
+ * escalation up to 4 (1 + header + nb*(4 + hzr_max_compressed_size(nch*ns)),
+ * hzr_encode.c:489-497, signal_packer_base.cpp:83-95). */
+size_t rspt_hip_max_compressed_size(const rspt_hip_packer* p);
+
+/* Input bytes per block: bps*nch*ns. */
+size_t rspt_hip_block_bytes(const rspt_hip_packer* p);
+
+/* Current nr_bytes_to_compress_ (signal_packer_xdelta_hzr.cpp:39,66): the
+ * state that mutates on escalation and must match between compressor and
+ * decompressor because it is not in the stream.  Synchronises the stream. */
+unsigned rspt_hip_current_nb(rspt_hip_packer* p);
+/* Set it (a decoder fed streams from another instance needs this). */
+int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb);
+
+/* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
+
+/* Grow the workspace so that up to max_blocks blocks can go through one
+ * launch sequence.  Called implicitly by the batch entry points; call it
+ * yourself to keep allocation out of a timed region. */
+int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks);
+
+/* Compress nblocks independent blocks that are resident in device memory.
+ * Semantics = nblocks successive compress() calls on one packer instance
+ * (including the persistent nb escalation, in block order).
+ *   d_src      nblocks * rspt_hip_block_bytes() bytes, blocks back to back
+ *   d_dst      block b's stream is written at d_dst + b*dst_stride
+ *   d_sizes    nblocks uint64: stream length of block b; if it would not fit
+ *              dst_stride nothing is written for that block and bit 63 is set
+ *   stream     hipStream_t (as void*) to enqueue on; NULL is the HIP null
+ *              stream, as everywhere in HIP.  rspt_hip_stream() returns the
+ *              handle's own stream for callers that want that one.
+ * Asynchronous: returns after enqueueing. */
+int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nblocks, void* d_dst, size_t dst_stride,
+                                uint64_t* d_sizes, void* stream);
+
+/* Decompress nblocks streams resident in device memory (stream b at
+ * d_src + b*src_stride) into d_dst (nblocks * rspt_hip_block_bytes() bytes).
+ * d_consumed[b] = bytes of stream b used; bit 63 set = malformed stream. */
+int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, size_t nblocks, void* d_dst,
+                                  uint64_t* d_consumed, void* stream);
+
+/* The handle's own (non-blocking) stream, as a hipStream_t. */
+void* rspt_hip_stream(rspt_hip_packer* p);
+
+/* Wait for the handle's own stream. */
+int rspt_hip_synchronize(rspt_hip_packer* p);
+
+/* ---- measurement hooks ---------------------------------------------------- */
+
+/* When enabled, every batch call brackets each kernel of the sequence with
+ * HIP events on the launch stream.  rspt_hip_stage_times() then synchronises
+ * and returns, for the LAST batch call, the per-stage elapsed milliseconds.
+ * Stage names are returned by rspt_hip_stage_name(i). */
+int rspt_hip_set_profiling(rspt_hip_packer* p, int on);
+int rspt_hip_stage_count(const rspt_hip_packer* p);
+const char* rspt_hip_stage_name(const rspt_hip_packer* p, int i);
+int rspt_hip_stage_times(rspt_hip_packer* p, float* ms, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSPT_HIP_H_ */

@@ -1,0 +1,239 @@
+"""Python host binding of the C ABI (include/rspt_hip.h) in librspt_hip.so.
+
+Mirrors the reference's operator interface for this path -- the i_signal_packer
+factories and compress()/decompress() of lib_rspt/signal_packer.h:29-73 -- so
+that tests read like the reference's own harness (lib_rspt_test/rspt_test.cpp:58-112).
+torch is used only for device memory and streams in the batched, device-resident
+calls; nothing here computes.  There is NO CPU fallback: if the HIP library or a
+gfx950 device is missing every constructor raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+KIND_HZR, KIND_XDELTA_HZR, KIND_DCT, KIND_HADAMARD = 0, 1, 2, 3
+KINDS = {"hzr": 0, "xdelta_hzr": 1, "dct": 2, "hadamard": 3}
+
+# every symbol include/rspt_hip.h declares (tests check the library exports them all)
+C_ABI_SYMBOLS = [
+    "rspt_hip_status_string", "rspt_hip_last_hip_error", "rspt_hip_device_count", "rspt_hip_packer_create",
+    "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
+    "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
+    "rspt_hip_decompress_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
+    "rspt_hip_stage_name", "rspt_hip_stage_times",
+]
+
+_u8p = C.POINTER(C.c_uint8)
+_szp = C.POINTER(C.c_size_t)
+_lib = None
+
+
+class RsptHipError(RuntimeError):
+    def __init__(self, where, status, hip_error=0):
+        self.status, self.hip_error = status, hip_error
+        msg = lib().rspt_hip_status_string(status).decode() if _lib is not None else str(status)
+        super().__init__("%s: %s (status %d, hipError %d)" % (where, msg, status, hip_error))
+
+
+def lib():
+    """Load (building if stale and hipcc is present) librspt_hip.so.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        path = _build.build()
+    if not os.path.exists(path):
+        raise RuntimeError("rspt_amd: %s is missing and cannot be built here; there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.rspt_hip_status_string.restype, L.rspt_hip_status_string.argtypes = C.c_char_p, [C.c_int]
+    L.rspt_hip_last_hip_error.restype, L.rspt_hip_last_hip_error.argtypes = C.c_int, [C.c_void_p]
+    L.rspt_hip_device_count.restype, L.rspt_hip_device_count.argtypes = C.c_int, []
+    L.rspt_hip_packer_create.restype = C.c_int
+    L.rspt_hip_packer_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+    L.rspt_hip_packer_destroy.restype, L.rspt_hip_packer_destroy.argtypes = None, [C.c_void_p]
+    L.rspt_hip_compress.restype, L.rspt_hip_compress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _szp]
+    L.rspt_hip_decompress.restype, L.rspt_hip_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
+    L.rspt_hip_max_compressed_size.restype, L.rspt_hip_max_compressed_size.argtypes = C.c_size_t, [C.c_void_p]
+    L.rspt_hip_block_bytes.restype, L.rspt_hip_block_bytes.argtypes = C.c_size_t, [C.c_void_p]
+    L.rspt_hip_current_nb.restype, L.rspt_hip_current_nb.argtypes = C.c_uint, [C.c_void_p]
+    L.rspt_hip_set_nb.restype, L.rspt_hip_set_nb.argtypes = C.c_int, [C.c_void_p, C.c_uint]
+    L.rspt_hip_reserve.restype, L.rspt_hip_reserve.argtypes = C.c_int, [C.c_void_p, C.c_size_t]
+    L.rspt_hip_compress_batch_dev.restype = C.c_int
+    L.rspt_hip_compress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.rspt_hip_decompress_batch_dev.restype = C.c_int
+    L.rspt_hip_decompress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rspt_hip_synchronize.restype, L.rspt_hip_synchronize.argtypes = C.c_int, [C.c_void_p]
+    L.rspt_hip_stream.restype, L.rspt_hip_stream.argtypes = C.c_void_p, [C.c_void_p]
+    L.rspt_hip_set_profiling.restype, L.rspt_hip_set_profiling.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    L.rspt_hip_stage_count.restype, L.rspt_hip_stage_count.argtypes = C.c_int, [C.c_void_p]
+    L.rspt_hip_stage_name.restype, L.rspt_hip_stage_name.argtypes = C.c_char_p, [C.c_void_p, C.c_int]
+    L.rspt_hip_stage_times.restype, L.rspt_hip_stage_times.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    # the C++ factories behind the same library (include/signal_packer.h), via their C shim
+    L.rspt_cxx_new.restype, L.rspt_cxx_new.argtypes = C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.rspt_cxx_delete.restype, L.rspt_cxx_delete.argtypes = None, [C.c_int, C.c_void_p]
+    L.rspt_cxx_compress.restype, L.rspt_cxx_compress.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _szp]
+    L.rspt_cxx_decompress.restype, L.rspt_cxx_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
+    _lib = L
+    return L
+
+
+def _as_u8(buf):
+    a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf.view(np.uint8).reshape(-1)
+    return np.ascontiguousarray(a)
+
+
+class SignalPacker:
+    """One i_signal_packer instance on one GPU."""
+
+    def __init__(self, kind, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, nr_bytes_to_encode=3, device=0):
+        self._L = lib()
+        self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
+        self.bps, self.nch, self.ns = bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel
+        h = C.c_void_p()
+        rc = self._L.rspt_hip_packer_create(C.byref(h), self.kind, self.bps, self.nch, self.ns, nr_bytes_to_encode, device)
+        if rc != 0:
+            raise RsptHipError("rspt_hip_packer_create", rc)
+        self._h = h
+        self.block_bytes = self._L.rspt_hip_block_bytes(h)
+        self.max_compressed_size = self._L.rspt_hip_max_compressed_size(h)
+
+    def _check(self, where, rc):
+        if rc != 0:
+            raise RsptHipError(where, rc, self._L.rspt_hip_last_hip_error(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rspt_hip_packer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- i_signal_packer::compress / decompress (host buffers) ----------------
+    def compress(self, src, dst_max_len=None):
+        a = _as_u8(src)
+        assert a.size == self.block_bytes, (a.size, self.block_bytes)
+        cap = dst_max_len if dst_max_len is not None else 2 * self.block_bytes + 4096
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check("rspt_hip_compress", self._L.rspt_hip_compress(self._h, a.ctypes.data, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def decompress(self, stream):
+        s = _as_u8(stream)
+        out = np.empty(self.block_bytes, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check("rspt_hip_decompress", self._L.rspt_hip_decompress(self._h, s.ctypes.data, C.byref(n), out.ctypes.data))
+        return out.tobytes(), n.value
+
+    @property
+    def nb(self):
+        return self._L.rspt_hip_current_nb(self._h)
+
+    def set_nb(self, nb):
+        self._check("rspt_hip_set_nb", self._L.rspt_hip_set_nb(self._h, nb))
+
+    # -- device-resident batches (torch tensors carry the memory) --------------
+    def reserve(self, nblocks):
+        self._check("rspt_hip_reserve", self._L.rspt_hip_reserve(self._h, nblocks))
+
+    def compress_batch(self, d_src, d_dst=None, d_sizes=None, dst_stride=None, stream=None):
+        """d_src: uint8 cuda tensor [nblocks, block_bytes].  Returns (d_dst, d_sizes);
+        asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+
+        assert d_src.is_cuda and d_src.dtype == torch.uint8 and d_src.is_contiguous()
+        nblocks = d_src.numel() // self.block_bytes
+        assert nblocks * self.block_bytes == d_src.numel()
+        if dst_stride is None:
+            dst_stride = (self.max_compressed_size + 255) // 256 * 256 if d_dst is None else d_dst.numel() // nblocks
+        if d_dst is None:
+            d_dst = torch.empty((nblocks, dst_stride), dtype=torch.uint8, device=d_src.device)
+        if d_sizes is None:
+            d_sizes = torch.empty(nblocks, dtype=torch.int64, device=d_src.device)
+        st = stream if stream is not None else torch.cuda.current_stream(d_src.device).cuda_stream
+        rc = self._L.rspt_hip_compress_batch_dev(self._h, d_src.data_ptr(), nblocks, d_dst.data_ptr(), dst_stride, d_sizes.data_ptr(), st)
+        self._check("rspt_hip_compress_batch_dev", rc)
+        return d_dst, d_sizes
+
+    def decompress_batch(self, d_streams, nblocks, src_stride, d_out=None, d_consumed=None, stream=None):
+        import torch
+
+        if d_out is None:
+            d_out = torch.empty((nblocks, self.block_bytes), dtype=torch.uint8, device=d_streams.device)
+        if d_consumed is None:
+            d_consumed = torch.empty(nblocks, dtype=torch.int64, device=d_streams.device)
+        st = stream if stream is not None else torch.cuda.current_stream(d_streams.device).cuda_stream
+        rc = self._L.rspt_hip_decompress_batch_dev(self._h, d_streams.data_ptr(), src_stride, nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
+        self._check("rspt_hip_decompress_batch_dev", rc)
+        return d_out, d_consumed
+
+    def synchronize(self):
+        self._check("rspt_hip_synchronize", self._L.rspt_hip_synchronize(self._h))
+
+    # -- measurement -------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._L.rspt_hip_set_profiling(self._h, int(on))
+
+    def stage_times(self):
+        n = self._L.rspt_hip_stage_count(self._h)
+        ms = (C.c_float * n)()
+        self._check("rspt_hip_stage_times", self._L.rspt_hip_stage_times(self._h, ms, n))
+        return {self._L.rspt_hip_stage_name(self._h, i).decode(): float(ms[i]) for i in range(n)}
+
+
+# factory names of lib_rspt/signal_packer.h:59-69
+def new_xdelta_hzr(bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, nr_bytes_to_encode, device=0):
+    return SignalPacker(KIND_XDELTA_HZR, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, nr_bytes_to_encode, device)
+
+
+def new_hzr(bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, device=0):
+    return SignalPacker(KIND_HZR, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, 4, device)
+
+
+def new_dct(bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, device=0):
+    return SignalPacker(KIND_DCT, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, 2, device)
+
+
+def new_hadamard(bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, device=0):
+    return SignalPacker(KIND_HADAMARD, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, 3, device)
+
+
+class CxxSignalPacker:
+    """Drives the C++ i_signal_packer factories of include/signal_packer.h themselves
+    (through the tiny C shim in signal_packer_hip.cpp) -- the reference-facing surface."""
+
+    def __init__(self, kind, bps, nch, ns, nb=3):
+        self._L = lib()
+        self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
+        self.block_bytes = bps * nch * ns
+        self._p = self._L.rspt_cxx_new(self.kind, bps, nch, ns, nb)
+        if not self._p:
+            raise RuntimeError("i_signal_packer factory failed")
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._L.rspt_cxx_delete(self.kind, self._p)
+            self._p = None
+
+    def compress(self, src):
+        a = _as_u8(src)
+        cap = 2 * self.block_bytes + 4096
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._L.rspt_cxx_compress(self._p, a.ctypes.data, out.ctypes.data, cap, C.byref(n))
+        return out[: n.value].tobytes()
+
+    def decompress(self, stream):
+        s = _as_u8(stream)
+        out = np.empty(self.block_bytes, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._L.rspt_cxx_decompress(self._p, s.ctypes.data, C.byref(n), out.ctypes.data)
+        return out.tobytes(), n.value, rc

@@ -1,0 +1,233 @@
+// common.hpp -- shared definitions for the gfx950 signal_packer kernels.
+//
+// Data model (names follow the reference's domain):
+//   block        one compress() call: nch x ns samples of bps bytes, interleaved
+//                sample-major (lib_signalpacker/utils.cpp:123-191)
+//   plane k      byte k of every transformed int32, flat channel-major order,
+//                N = nch*ns bytes (signal_packer_base.cpp:40-68)
+//   hzr block    <= 65536 consecutive bytes of one plane (hzr_encode.c:528-539):
+//                the unit one workgroup encodes
+//   granule      16 consecutive bytes of an hzr block: the unit one lane owns
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rspt {
+
+constexpr uint32_t kHzrBlock = 65536;  // hzr_internal.h:109
+constexpr int kNumSym = 261;           // hzr_internal.h:114
+constexpr uint32_t kRunCap = 16662;    // hzr_internal.h:121
+constexpr int kSymStride = 264;        // per-block stride of hist[] / cw[] rows (u32)
+constexpr int kTdescWords = 92;        // >= ceil((261*10+260)/32)=90, padded
+constexpr int kWave = 64;
+constexpr int kEncThreads = 1024;      // one hzr block per 1024-thread workgroup
+constexpr int kEncWaves = kEncThreads / kWave;
+constexpr int kMaxPlanes = 4;
+
+enum : uint32_t { kModeCopy = 0, kModeHuff = 1, kModeFill = 2, kModeSkip = 3 };
+
+// Shape of one packer, passed to kernels by value.
+struct Geom {
+    uint32_t bps, nch, ns;
+    uint32_t N;             // nch*ns  (< 2^31, as in the reference's int indices)
+    uint32_t nblk;          // hzr blocks per plane = ceil(N/65536)
+    uint32_t hdr_len;       // 0, or 3*nch for dct/hadamard (means header)
+    uint32_t method;        // stream method byte (signal_packer_base.cpp:83)
+    uint32_t kind;          // rspt_hip_kind
+    uint64_t plane_stride;  // bytes between planes in the workspace (N rounded up to 256)
+    uint64_t block_bytes;   // bps*nch*ns
+};
+
+// CRC-32C constants for the parallel checksum (tools/kernel_model.py:crc_parallel).
+struct CrcConsts {
+    uint32_t table[256];      // byte-at-a-time LUT, reflected poly 0x82F63B78 (hzr_crc32c.c:32)
+    uint32_t lane_shift[64];  // x^(128*(63-l))
+    uint32_t wave_shift[16];  // x^(8*1024*(15-w))
+    uint32_t row_shift;       // x^(8*16384)
+    uint32_t prefix;          // 4 bytes X (LE) with raw_crc(X) = 0xFFFFFFFF
+    uint32_t pad[2];
+};
+
+// Per-hzr-block record written by k_tree, read by k_layout and k_encode.
+struct BlockMeta {
+    uint32_t mode;         // kMode*
+    uint32_t payload_len;  // bytes after the 7-byte block header
+    uint32_t tree_bits;    // length of the tree description (mode 1)
+    uint32_t fill;         // fill byte (mode 2)
+};
+
+__device__ __forceinline__ uint32_t hb_index(const Geom& g, uint32_t b, uint32_t k, uint32_t j) {
+    return (b * kMaxPlanes + k) * g.nblk + j;
+}
+
+// ---------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;  // identical in every lane
+}
+
+__device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_add_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (l >= (uint32_t)d) v += o;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// zero-run chaining: a scan element is (all<<31 | count).  "all" = everything
+// covered so far is zero; count = zeros adjacent to the open side.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kZAll = 0x80000000u;
+constexpr uint32_t kZIdentity = kZAll;  // (all=1, count=0)
+
+// `far` is the side further from the open end, `near` the side next to it.
+__device__ __forceinline__ uint32_t zcomb(uint32_t far, uint32_t near) {
+    return (near & kZAll) ? ((far & kZAll) | ((far & ~kZAll) + (near & ~kZAll))) : near;
+}
+
+// inclusive forward scan: result at lane l covers lanes 0..l, open side = after lane l
+__device__ __forceinline__ uint32_t wave_zscan_fwd(uint32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (l >= (uint32_t)d) v = zcomb(o, v);
+    }
+    return v;
+}
+
+// inclusive backward scan: result at lane l covers lanes l..63, open side = before lane l
+__device__ __forceinline__ uint32_t wave_zscan_bwd(uint32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_down((int)v, d, 64);
+        if (l + (uint32_t)d < 64u) v = zcomb(o, v);
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// granule analysis
+// ---------------------------------------------------------------------------
+// 0x80 in every byte of w that is zero (exact, no borrow artefacts)
+__device__ __forceinline__ uint32_t zero_byte_flags(uint32_t w) {
+    uint32_t t = (w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    return ~(t | w | 0x7F7F7F7Fu);
+}
+
+// 4-bit mask: bit i set iff byte i of w is zero
+__device__ __forceinline__ uint32_t zero_nibble(uint32_t w) {
+    return (((zero_byte_flags(w) >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+
+struct Granule {
+    uint32_t w[4];  // 16 bytes, little-endian
+    uint32_t nv;    // valid bytes (0..16)
+    uint32_t zm;    // bit i set iff byte i is valid and zero
+};
+
+__device__ __forceinline__ void granule_finish(Granule& g) {
+    uint32_t m = zero_nibble(g.w[0]) | (zero_nibble(g.w[1]) << 4) | (zero_nibble(g.w[2]) << 8) | (zero_nibble(g.w[3]) << 12);
+    g.zm = m & ((1u << g.nv) - 1u);
+}
+
+__device__ __forceinline__ uint32_t granule_byte(const Granule& g, uint32_t i) { return (g.w[i >> 2] >> ((i & 3) * 8)) & 0xFFu; }
+
+// leading zeros (capped at nv), as a chain element for the BACKWARD scan
+__device__ __forceinline__ uint32_t granule_lead_elem(const Granule& g) {
+    uint32_t lead = (uint32_t)__builtin_ctz(~g.zm | (1u << g.nv));
+    return (g.nv == 16 && g.zm == 0xFFFFu) ? (kZAll | 16u) : lead;
+}
+
+// trailing zeros, as a chain element for the FORWARD scan
+__device__ __forceinline__ uint32_t granule_trail_elem(const Granule& g) {
+    if (g.nv != 16) return 0;  // a partial granule ends the block
+    if (g.zm == 0xFFFFu) return kZAll | 16u;
+    uint32_t nz = (~g.zm) & 0xFFFFu;
+    return (uint32_t)__builtin_clz(nz) - 16u;
+}
+
+// zero-run length -> symbol / extra bits (hzr_internal.h:117-121, hzr_encode.c:422-447)
+__device__ __forceinline__ uint32_t run_symbol(uint32_t z) {
+    return z == 1 ? 0u : z == 2 ? 256u : z <= 6 ? 257u : z <= 22 ? 258u : z <= 278 ? 259u : 260u;
+}
+__device__ __forceinline__ uint32_t run_extra_bits(uint32_t sym) {
+    return sym == 257 ? 2u : sym == 258 ? 4u : sym == 259 ? 8u : sym == 260 ? 14u : 0u;
+}
+__device__ __forceinline__ uint32_t run_extra_value(uint32_t sym, uint32_t z) {
+    return sym == 257 ? z - 3 : sym == 258 ? z - 7 : sym == 259 ? z - 23 : sym == 260 ? z - 279 : 0u;
+}
+
+// Walk the tokens that START in granule g.  zb = zeros immediately before the
+// granule, za = zeros immediately after it (tools/kernel_model.py:granule_tokens).
+// f(sym, run_length) is called once per token in stream order.
+template <typename F>
+__device__ __forceinline__ void granule_for_each_token(const Granule& g, uint32_t zb, uint32_t za, F&& f) {
+    uint32_t dist = zb;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+        if (i < g.nv) {
+            uint32_t x = granule_byte(g, i);
+            if (x != 0) {
+                f(x, 0u);
+                dist = 0;
+            } else {
+                if (dist == 0 || dist == kRunCap || dist == 2 * kRunCap || dist == 3 * kRunCap) {
+                    uint32_t ahead = (uint32_t)__builtin_ctz(~(g.zm >> i) | (1u << (g.nv - i)));
+                    uint32_t rem = ahead + ((i + ahead == g.nv) ? za : 0u);
+                    uint32_t z = rem < kRunCap ? rem : kRunCap;
+                    f(run_symbol(z), z);
+                }
+                ++dist;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GF(2) arithmetic for CRC-32C in the reflected domain (bit 31 = x^0)
+// ---------------------------------------------------------------------------
+constexpr uint32_t kCrcPoly = 0x82F63B78u;
+
+__host__ __device__ inline uint32_t gf_mul(uint32_t a, uint32_t b) {
+    uint32_t r = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        r ^= b & (0u - ((a >> (31 - i)) & 1u));
+        b = (b >> 1) ^ (kCrcPoly & (0u - (b & 1u)));
+    }
+    return r;
+}
+
+}  // namespace rspt

@@ -1,0 +1,544 @@
+// hzr_kernels.hip -- the hzr block codec (RLE of zero runs + per-block Huffman,
+// LSB-first bit stream, CRC-32C) as gfx950 kernels.  Bit-exact with
+// lib_hzr/hzr_encode.c; the parallel formulations are modelled and checked on
+// the CPU in tools/kernel_model.py + tests/test_kernel_model.py.
+//
+//   k_hist    one 1024-thread workgroup per hzr block: zero-run tokenizer
+//             (hzr_encode.c:133-173) on 16-byte granules + 261-bin histogram
+//   k_tree    one wave per hzr block: Fill test (:285-305), Huffman tree with
+//             the reference's tie-break (:222-283), codes + pre-order tree
+//             description (:177-219), exact payload size -> block mode (:377-469)
+//   k_layout  one workgroup per block: sizes -> stream offsets, stream framing
+//             (signal_packer_base.cpp:69-95, hzr_encode.c:521-522)
+//   k_encode  one 1024-thread workgroup per hzr block: emit codes into an LDS
+//             image of the payload (:410-457), parallel CRC-32C
+//             (hzr_crc32c.c:77-84), block header (:475-481), coalesced copy-out
+#include "common.hpp"
+
+namespace rspt {
+
+// ===========================================================================
+// shared: load the 4 granules a lane owns and chain the zero runs across the
+// workgroup.  Wave w owns bytes [4096w, 4096w+4096) of the hzr block as 4 rows
+// of 1 KiB; lane l of row r owns the granule at 4096w + 1024r + 16l, so every
+// global load is a fully coalesced 1 KiB wave access.
+// ===========================================================================
+struct LaneBlock {
+    Granule g[4];
+    uint32_t zb[4];  // zeros immediately before granule r (cut at the block start)
+    uint32_t za[4];  // zeros immediately after granule r (cut at the block end)
+};
+
+// scratch: 2*kEncWaves uint32
+__device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, uint32_t in_size, LaneBlock& L, uint32_t* scratch) {
+    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = w * 4096 + r * 1024 + l * 16;
+        Granule& g = L.g[r];
+        g.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g.nv) v = *reinterpret_cast<const uint4*>(in + pos);  // plane rows are padded: a partial granule may over-read, masked below
+        g.w[0] = v.x;
+        g.w[1] = v.y;
+        g.w[2] = v.z;
+        g.w[3] = v.w;
+        granule_finish(g);
+    }
+    // forward chain (zeros before): rows in order, carry = everything before the row
+    uint32_t carry = kZIdentity;
+    uint32_t fwd_incl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t inc = wave_zscan_fwd(granule_trail_elem(L.g[r]));
+        uint32_t exc = (uint32_t)__shfl_up((int)inc, 1, 64);
+        if (l == 0) exc = kZIdentity;
+        fwd_incl[r] = zcomb(carry, exc);  // wave-local exclusive prefix for this lane
+        carry = zcomb(carry, (uint32_t)__shfl((int)inc, 63, 64));
+    }
+    const uint32_t wave_fwd = carry;
+    // backward chain (zeros after): rows in reverse
+    carry = kZIdentity;
+    uint32_t bwd_incl[4];
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+        uint32_t inc = wave_zscan_bwd(granule_lead_elem(L.g[r]));
+        uint32_t exc = (uint32_t)__shfl_down((int)inc, 1, 64);
+        if (l == 63) exc = kZIdentity;
+        bwd_incl[r] = zcomb(carry, exc);
+        carry = zcomb(carry, (uint32_t)__shfl((int)inc, 0, 64));
+    }
+    const uint32_t wave_bwd = carry;
+    if (l == 0) {
+        scratch[w] = wave_fwd;
+        scratch[kEncWaves + w] = wave_bwd;
+    }
+    __syncthreads();
+    uint32_t pre = kZIdentity;  // everything before this wave
+    for (uint32_t i = 0; i < w; ++i) pre = zcomb(pre, scratch[i]);
+    uint32_t post = kZIdentity;  // everything after this wave
+    for (int i = kEncWaves - 1; i > (int)w; --i) post = zcomb(post, scratch[kEncWaves + i]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        L.zb[r] = zcomb(pre, fwd_incl[r]) & ~kZAll;
+        L.za[r] = zcomb(post, bwd_incl[r]) & ~kZAll;
+    }
+    __syncthreads();  // scratch may be reused by the caller
+}
+
+// ===========================================================================
+// k_hist
+// ===========================================================================
+__global__ __launch_bounds__(kEncThreads) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+                                                     uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[kSymStride];
+    __shared__ uint32_t s_scr[2 * kEncWaves];
+    const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
+    if (k >= nbuse[b]) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    if (tid < kSymStride) s_hist[tid] = 0;
+    LaneBlock L;
+    load_and_chain(in, in_size, L, s_scr);  // contains the barrier that publishes the zeroed histogram
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        granule_for_each_token(L.g[r], L.zb[r], L.za[r], [&](uint32_t sym, uint32_t) { atomicAdd(&s_hist[sym], 1u); });
+    }
+    __syncthreads();
+    if (tid < kSymStride) hist[(size_t)hb_index(g, b, k, j) * kSymStride + tid] = s_hist[tid];
+}
+
+// ===========================================================================
+// k_tree: one wave per hzr block, 4 waves per workgroup
+// ===========================================================================
+constexpr int kTreeWaves = 4;
+constexpr uint32_t kKeyMax = 0xFFFFFFFFu;
+
+struct TreeLds {
+    uint32_t key[9 * 64];  // node keys: count<<10 | (1023 - index); index order = creation order
+    uint32_t up[2 * kNumSym];     // parent | isB<<10 | add<<11
+    uint16_t sbits[2 * kNumSym];  // description bits of the subtree
+    uint16_t leafsym[kSymStride];
+    uint32_t tdesc[kTdescWords];
+};
+
+// The merge loop with the live keys in NREG registers per lane (node i lives
+// in lane i&63, register i>>6).  Each iteration extracts the two smallest keys
+// = the reference's `<=` scan (hzr_encode.c:251-260): count ascending, index
+// descending.
+template <int NREG>
+__device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
+    const uint32_t l = lane_id();
+    uint32_t kreg[NREG];
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) kreg[r] = t.key[r * 64 + l];
+    for (uint32_t it = 0; it + 1 < S; ++it) {
+        uint32_t m = kreg[0];
+#pragma unroll
+        for (int r = 1; r < NREG; ++r) m = min(m, kreg[r]);
+        const uint32_t m1 = wave_min_u32(m);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m1 ? kKeyMax : kreg[r];
+        m = kreg[0];
+#pragma unroll
+        for (int r = 1; r < NREG; ++r) m = min(m, kreg[r]);
+        const uint32_t m2 = wave_min_u32(m);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m2 ? kKeyMax : kreg[r];
+        const uint32_t i1 = 1023u - (m1 & 1023u), i2 = 1023u - (m2 & 1023u);
+        const uint32_t n = S + it;
+        const uint32_t nk = (((m1 >> 10) + (m2 >> 10)) << 10) | (1023u - n);
+#pragma unroll
+        for (int r = 0; r < NREG; ++r)
+            if ((n >> 6) == (uint32_t)r && (n & 63u) == l) kreg[r] = nk;
+        if (l == 0) {
+            const uint32_t sb1 = t.sbits[i1], sb2 = t.sbits[i2];
+            t.sbits[n] = (uint16_t)(1u + sb1 + sb2);
+            t.up[i1] = n | (0u << 10) | (1u << 11);          // child_a: code bit 0
+            t.up[i2] = n | (1u << 10) | ((1u + sb1) << 11);  // child_b: code bit 1, described after a's subtree
+        }
+    }
+}
+
+__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, Geom g, const uint32_t* __restrict__ nbuse,
+                                                         uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
+                                                         BlockMeta* __restrict__ meta) {
+    __shared__ TreeLds s_t[kTreeWaves];
+    const uint32_t l = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t hb = blockIdx.x * kTreeWaves + wv;
+    if (hb >= nhb_total) return;
+    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    TreeLds& t = s_t[wv];
+    if (k >= nbuse[b]) {
+        if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
+        return;
+    }
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    const uint32_t* h = hist + (size_t)hb * kSymStride;
+
+    // ---- leaves in ascending symbol order (hzr_encode.c:226-234) ----------
+    uint32_t cnt[5], idx[5];
+    uint32_t base = 0, nonzero_syms = 0, zero_kind = 0, fillval = 0;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t s = r * 64 + l;
+        cnt[r] = s < (uint32_t)kNumSym ? h[s] : 0u;
+        const unsigned long long bal = __ballot(cnt[r] != 0);
+        idx[r] = base + (uint32_t)__popcll(bal & ((1ull << l) - 1ull));
+        base += (uint32_t)__popcll(bal);
+        // OnlySingleCode (hzr_encode.c:285-305): all zero-type symbols count as one code
+        const bool is_zero_kind = (s == 0) || (s >= 256);
+        const unsigned long long nzb = __ballot(cnt[r] != 0 && !is_zero_kind);
+        nonzero_syms += (uint32_t)__popcll(nzb);
+        zero_kind |= __ballot(cnt[r] != 0 && is_zero_kind) ? 1u : 0u;
+        if (nzb) fillval = max(fillval, (uint32_t)(r * 64 + (63 - __builtin_clzll(nzb))));
+    }
+    const uint32_t S = base;
+    uint32_t* cwo = cw + (size_t)hb * kSymStride;
+    if (zero_kind + nonzero_syms == 1) {  // EncodeFill (hzr_encode.c:341-367)
+        if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, zero_kind ? 0u : fillval};
+        return;
+    }
+
+    // ---- node arrays -------------------------------------------------------
+    for (uint32_t i = l; i < 9 * 64; i += 64) t.key[i] = kKeyMax;
+    for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) t.tdesc[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        if (cnt[r]) {
+            t.key[idx[r]] = (cnt[r] << 10) | (1023u - idx[r]);
+            t.sbits[idx[r]] = 10;  // leaf = '1' + 9-bit symbol
+            t.leafsym[idx[r]] = (uint16_t)(r * 64 + l);
+        }
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t nnodes = 2 * S - 1;
+    const uint32_t nreg = (nnodes + 63) >> 6;
+    if (nreg <= 1)
+        merge_loop<1>(t, S);
+    else if (nreg <= 2)
+        merge_loop<2>(t, S);
+    else if (nreg <= 3)
+        merge_loop<3>(t, S);
+    else if (nreg <= 5)
+        merge_loop<5>(t, S);
+    else
+        merge_loop<9>(t, S);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- per-leaf walk to the root: code, length, description offset -------
+    const uint32_t root = nnodes - 1;
+    const uint32_t tree_bits = t.sbits[root];
+    uint32_t bits_sum = 0;
+    for (uint32_t i = l; i < S; i += 64) {
+        uint32_t cur = i, code = 0, len = 0, off = 0;
+        while (cur != root && len < 64) {  // depth <= 22 for <= 65536 tokens; the bound only guards against a corrupted link
+            const uint32_t u = t.up[cur];
+            code = (code << 1) | ((u >> 10) & 1u);
+            off += u >> 11;
+            ++len;
+            cur = u & 1023u;
+        }
+        const uint32_t sym = t.leafsym[i];
+        cwo[sym] = code | (len << 24);
+        // description: '1' then the 9-bit symbol, LSB first (hzr_encode.c:184-191)
+        const uint32_t v = 1u | (sym << 1);
+        const uint32_t wi = off >> 5, sh = off & 31u;
+        atomicOr(&t.tdesc[wi], v << sh);
+        if (sh > 22) atomicOr(&t.tdesc[wi + 1], v >> (32 - sh));
+        bits_sum += h[sym] * (len + run_extra_bits(sym));
+    }
+    bits_sum = wave_add_u32(bits_sum);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
+    for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
+    if (l == 0) {
+        const uint32_t total_bits = tree_bits + bits_sum;
+        const uint32_t nbytes = (total_bits + 7) >> 3;
+        // Huffman iff the payload fits in in_size bytes and is < 65536 (hzr_encode.c:377-382,463-469)
+        if (nbytes <= in_size && nbytes < kHzrBlock)
+            meta[hb] = BlockMeta{kModeHuff, nbytes, tree_bits, 0};
+        else
+            meta[hb] = BlockMeta{kModeCopy, in_size, 0, 0};
+    }
+}
+
+// ===========================================================================
+// k_layout: one workgroup per block.  Stream grammar:
+//   [method][means header][ per plane k<nb: u32 len_k, u32 N, hzr blocks... ]
+// ===========================================================================
+__device__ __forceinline__ void store_le32(uint8_t* p, uint32_t v) {
+    p[0] = (uint8_t)v;
+    p[1] = (uint8_t)(v >> 8);
+    p[2] = (uint8_t)(v >> 16);
+    p[3] = (uint8_t)(v >> 24);
+}
+
+__global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restrict__ nbuse, const BlockMeta* __restrict__ meta,
+                                               const uint8_t* __restrict__ means_hdr, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                               uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes) {
+    __shared__ uint64_t s_part[256];
+    __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t nb = nbuse[b];
+    const uint32_t n = nb * g.nblk;  // hzr blocks of this block, (k,j) order
+    const uint32_t per = (n + 255) / 256;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    const uint32_t hb0 = hb_index(g, b, 0, 0);
+    auto enc_size = [&](uint32_t q) -> uint64_t {  // q = k*nblk + j
+        return 7ull + meta[hb0 + q].payload_len;
+    };
+    uint64_t sum = 0;
+    for (uint32_t q = lo; q < hi; ++q) sum += enc_size(q);
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint64_t run = 0;
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint64_t v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    // absolute offset of hzr block q: 1 + hdr + 8*(k+1) + sum of the encoded blocks before it
+    uint64_t run = s_part[tid];
+    const uint64_t head = 1ull + g.hdr_len;
+    for (uint32_t q = lo; q < hi; ++q) {
+        const uint32_t k = q / g.nblk;
+        out_off[hb0 + q] = head + 8ull * (k + 1) + run;
+        run += enc_size(q);
+        if ((q + 1) % g.nblk == 0) s_plane_end[k + 1] = run;  // encoded bytes up to the end of plane k
+    }
+    if (tid == 0) s_plane_end[0] = 0;
+    __syncthreads();
+    const uint64_t total = head + 8ull * nb + s_plane_end[nb];
+    const bool fits = total <= dst_stride;
+    if (tid == 0) sizes[b] = fits ? total : (total | (1ull << 63));
+    if (!fits) {  // tell k_encode to leave this block alone
+        for (uint32_t q = lo; q < hi; ++q) out_off[hb0 + q] = ~0ull;
+        return;
+    }
+    uint8_t* o = dst + (size_t)b * dst_stride;
+    if (tid == 0) o[0] = (uint8_t)g.method;  // signal_packer_base.cpp:83
+    for (uint32_t i = tid; i < g.hdr_len; i += 256) o[1 + i] = means_hdr[(size_t)b * g.hdr_len + i];  // :86-91
+    if (tid < nb) {
+        const uint32_t k = tid;
+        const uint64_t pstart = head + 8ull * k + s_plane_end[k];
+        const uint64_t plen = 4ull + (s_plane_end[k + 1] - s_plane_end[k]);  // hzr stream = master header + blocks
+        store_le32(o + pstart, (uint32_t)plen);                               // base.cpp:78
+        store_le32(o + pstart + 4, g.N);                                      // hzr_encode.c:521-522
+    }
+}
+
+// ===========================================================================
+// k_encode
+// ===========================================================================
+struct BitSink {
+    uint32_t* stage;
+    uint64_t acc;
+    uint32_t n;     // bits held in acc
+    uint32_t word;  // next staging word
+    __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
+        stage = s;
+        acc = 0;
+        n = bitpos & 31u;
+        word = bitpos >> 5;
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t len) {  // len <= 32, v has no bits above len
+        acc |= (uint64_t)v << n;
+        n += len;
+        if (n >= 32) {
+            atomicOr(&stage[word++], (uint32_t)acc);
+            acc >>= 32;
+            n -= 32;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n) atomicOr(&stage[word], (uint32_t)acc);
+    }
+};
+
+// message byte p of the virtual CRC input V = X || payload, payload coordinates
+// (p in [-4,0) addresses the 4 prefix bytes X, p < -4 is the zero front padding)
+__device__ __forceinline__ uint32_t vmsg_byte(const uint8_t* stage, int32_t p, uint32_t prefix) {
+    if (p >= 0) return stage[p];
+    if (p >= -4) return (prefix >> ((p + 4) * 8)) & 0xFFu;
+    return 0;
+}
+
+__global__ __launch_bounds__(kEncThreads) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+                                                       const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
+                                                       const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
+                                                       const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kHzrBlock / 4 + 8];
+    __shared__ uint32_t s_cw[kSymStride];
+    __shared__ uint32_t s_crctab[256];
+    __shared__ uint32_t s_scr[2 * kEncWaves];
+    __shared__ uint32_t s_wsum[kEncWaves];
+    __shared__ uint32_t s_crc;
+
+    const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
+    if (k >= nbuse[b]) return;
+    const uint32_t hb = hb_index(g, b, k, j);
+    const uint64_t off = out_off[hb];
+    if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
+    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const BlockMeta m = meta[hb];
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    uint8_t* stage8 = reinterpret_cast<uint8_t*>(s_stage);
+    const uint32_t L = m.payload_len;
+
+    if (tid < 256) s_crctab[tid] = cc->table[tid];
+
+    if (m.mode == kModeHuff) {
+        // zero the payload image (bits are OR-ed in)
+        for (uint32_t i = tid; i < kHzrBlock / 16 + 2; i += kEncThreads) reinterpret_cast<uint4*>(s_stage)[i] = make_uint4(0, 0, 0, 0);
+        if (tid < kSymStride) s_cw[tid] = cw[(size_t)hb * kSymStride + tid];
+        LaneBlock B;
+        load_and_chain(in, in_size, B, s_scr);  // barriers inside publish s_cw and the zeroed image
+        // tree description (hzr_encode.c:177-219)
+        const uint32_t twords = (m.tree_bits + 31) >> 5;
+        if (tid < twords) atomicOr(&s_stage[tid], tdesc[(size_t)hb * kTdescWords + tid]);
+        // pass 1: bits per granule
+        uint32_t nbits[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint32_t nb_ = 0;
+            granule_for_each_token(B.g[r], B.zb[r], B.za[r], [&](uint32_t sym, uint32_t) { nb_ += (s_cw[sym] >> 24) + run_extra_bits(sym); });
+            nbits[r] = nb_;
+        }
+        // exclusive bit offsets in byte order: wave w rows 0..3, lanes 0..63
+        uint32_t excl[4];
+        uint32_t run = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uint32_t inc = wave_scan_add(nbits[r]);
+            excl[r] = run + inc - nbits[r];
+            run += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+        if (l == 0) s_wsum[w] = run;
+        __syncthreads();
+        uint32_t wbase = m.tree_bits;
+        for (uint32_t i = 0; i < w; ++i) wbase += s_wsum[i];
+        // pass 2: emit (hzr_encode.c:410-457); code first, then the run's extra bits
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (nbits[r]) {
+                BitSink sink;
+                sink.start(s_stage, wbase + excl[r]);
+                granule_for_each_token(B.g[r], B.zb[r], B.za[r], [&](uint32_t sym, uint32_t z) {
+                    const uint32_t c = s_cw[sym];
+                    sink.put(c & 0x00FFFFFFu, c >> 24);
+                    const uint32_t eb = run_extra_bits(sym);
+                    if (eb) sink.put(run_extra_value(sym, z), eb);
+                });
+                sink.flush();
+            }
+        }
+    } else if (m.mode == kModeCopy) {
+        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block
+        for (uint32_t i = tid; i < kHzrBlock / 16; i += kEncThreads) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (i * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)i * 16);
+            reinterpret_cast<uint4*>(s_stage)[i] = v;
+        }
+    } else {  // Fill (hzr_encode.c:341-367): payload = the fill byte
+        if (tid == 0) s_stage[0] = m.fill;
+    }
+    __syncthreads();
+
+    // ---- CRC-32C of payload bytes [0, L) (tools/kernel_model.py:crc_parallel) ----
+    {
+        const uint32_t Lv = L + 4;
+        const uint32_t G = (Lv + 15) >> 4;
+        const uint32_t rows = (G + kEncThreads - 1) / kEncThreads;
+        const uint32_t lane_k = cc->lane_shift[l];
+        const uint32_t row_k = cc->row_shift;
+        const uint32_t prefix = cc->prefix;
+        const uint32_t sh = L & 3u;  // every granule starts at L (mod 16): one byte shift for all lanes
+        uint32_t acc = 0;
+        for (int rowE = (int)rows - 1; rowE >= 0; --rowE) {
+            const uint32_t ge = (uint32_t)rowE * kEncThreads + (kEncThreads - 1 - tid);
+            const int32_t hi = (int32_t)L - (int32_t)(16 * ge);  // exclusive end, payload coordinates
+            const int32_t lo = hi - 16;
+            uint32_t c = 0;
+            if (hi > -4) {
+                uint32_t d[4];
+                if (lo >= 0) {
+                    const uint32_t a = (uint32_t)lo >> 2;
+                    uint32_t x0 = s_stage[a], x1 = s_stage[a + 1], x2 = s_stage[a + 2], x3 = s_stage[a + 3];
+                    uint32_t x4 = sh ? s_stage[a + 4] : 0u;
+                    d[0] = __builtin_amdgcn_alignbyte(x1, x0, sh);
+                    d[1] = __builtin_amdgcn_alignbyte(x2, x1, sh);
+                    d[2] = __builtin_amdgcn_alignbyte(x3, x2, sh);
+                    d[3] = __builtin_amdgcn_alignbyte(x4, x3, sh);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v |= vmsg_byte(stage8, lo + q * 4 + e, prefix) << (8 * e);
+                        d[q] = v;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    c ^= d[q];
+                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
+                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
+                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
+                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
+                }
+            }
+            const unsigned long long any = __ballot(c != 0);
+            uint32_t red = 0;
+            if (any) red = wave_xor_u32(gf_mul(c, lane_k));
+            acc = gf_mul(acc, row_k) ^ red;
+        }
+        if (l == 0) s_wsum[w] = gf_mul(acc, cc->wave_shift[w]);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int i = 0; i < kEncWaves; ++i) t ^= s_wsum[i];
+            s_crc = ~t;
+        }
+        __syncthreads();
+    }
+
+    // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
+    uint8_t* o = dst + (size_t)b * dst_stride + off;
+    if (tid == 0) {
+        const uint32_t crc = s_crc;
+        o[0] = (uint8_t)(L - 1);
+        o[1] = (uint8_t)((L - 1) >> 8);
+        o[2] = (uint8_t)crc;
+        o[3] = (uint8_t)(crc >> 8);
+        o[4] = (uint8_t)(crc >> 16);
+        o[5] = (uint8_t)(crc >> 24);
+        o[6] = (uint8_t)m.mode;
+    }
+    uint8_t* po = o + 7;
+    const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
+    const uint32_t nd = (L - head) >> 2;
+    const uint32_t tail = L - head - 4 * nd;
+    if (tid < head) po[tid] = stage8[tid];
+    if (tid < tail) po[head + 4 * nd + tid] = stage8[head + 4 * nd + tid];
+    uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
+    for (uint32_t i = tid; i < nd; i += kEncThreads) {
+        // staging bytes [head+4i, head+4i+4): unaligned in LDS by (head & 3)
+        const uint32_t x0 = s_stage[i], x1 = s_stage[i + 1];
+        pw[i] = __builtin_amdgcn_alignbyte(x1, x0, head);
+    }
+}
+
+}  // namespace rspt

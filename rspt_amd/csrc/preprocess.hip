@@ -1,0 +1,286 @@
+// preprocess.hip -- front end of every packer: interleaved native samples ->
+// channel-major byte planes (and the xdelta pre-transform).
+//
+// Restates, fused into one pass over HBM:
+//   convert_native_to_i32   lib_signalpacker/utils.cpp:123-191 (LE branches)
+//   delta_encode            utils.cpp:193-202   } over the FLAT nch*ns array:
+//   offset_32(-128)         utils.cpp:215-219   } sample 0 of channel c follows
+//   xor_encode_32           utils.cpp:221-230   } the last sample of channel c-1
+//   byte-plane split        lib_signalpacker/signal_packer_base.cpp:40-68
+//   nb escalation test      signal_packer_xdelta_hzr.cpp:59-69, as the exact
+//                           "fits in nb bytes" reduction
+//
+// Layout.  The input is sample-major ([ns][nch][bps]), so a tile of T samples x
+// all channels is ONE contiguous byte range: it is loaded with 16-byte coalesced
+// reads into LDS, read back with lane<->channel (consecutive LDS words), and
+// the plane bytes go through a second LDS region so that every plane row leaves
+// as 16-byte coalesced stores (T contiguous bytes per channel per plane).
+#include "common.hpp"
+
+namespace rspt {
+
+template <int BPS>
+__device__ __forceinline__ int32_t sample_from_bytes(const uint8_t* p, bool aligned) {
+    if (BPS == 4) {
+        if (aligned) return *reinterpret_cast<const int32_t*>(p);
+        uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        return (int32_t)u;
+    } else if (BPS == 3) {
+        uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+        return (int32_t)(u << 8) >> 8;
+    } else if (BPS == 2) {
+        uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8);
+        return (int32_t)(u << 16) >> 16;
+    } else {
+        return (int32_t)(int8_t)p[0];
+    }
+}
+
+// p[flat] of block `blk`, straight from HBM; flat < 0 -> 0 (the transforms start from 0)
+template <int BPS>
+__device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom& g, int64_t flat) {
+    if (flat < 0) return 0;
+    uint32_t f = (uint32_t)flat;
+    uint32_t c = f / g.ns, s = f - c * g.ns;
+    return sample_from_bytes<BPS>(blk + ((size_t)s * g.nch + c) * BPS, false);
+}
+
+// One workgroup = one tile of T samples x all channels of one block.
+//   XDELTA  true : v = (p[i]-p[i-1]-128) ^ (p[i-1]-p[i-2]-128), flat order; accumulates needmask
+//           false: v = p (hzr packer)
+//   NPLANES planes written (4: nb may escalate up to 4 and the planes must be there)
+// LDS: [ in tile: T*nch*BPS + 16 ][ out: NPLANES*nch rows of (T+16) bytes ]
+template <int BPS, bool XDELTA>
+__global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t in_lds_bytes,
+                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.y;
+    const uint32_t s0 = blockIdx.x * T;
+    const uint32_t Tn = min(T, g.ns - s0);
+    const uint8_t* blk = src + (size_t)b * g.block_bytes;
+    const uint32_t rowb = g.nch * BPS;
+
+    // ---- phase 1: contiguous tile -> LDS, 16 B per lane --------------------
+    const size_t gs = (size_t)s0 * rowb;
+    const size_t ge = gs + (size_t)Tn * rowb;
+    const uintptr_t abs_s = reinterpret_cast<uintptr_t>(blk) + gs;
+    const uint32_t lo = (uint32_t)(abs_s & 15);  // tile starts `lo` bytes into its first 16-byte chunk
+    const uint8_t* abase = reinterpret_cast<const uint8_t*>(abs_s - lo);
+    const uint32_t span = lo + (uint32_t)(ge - gs);
+    for (uint32_t o = tid * 16; o < span; o += 256 * 16) {
+        uint4 v = *reinterpret_cast<const uint4*>(abase + o);
+        *reinterpret_cast<uint4*>(lds + o) = v;
+    }
+    __syncthreads();
+
+    uint8_t* out = lds + in_lds_bytes;
+    const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
+    const bool aligned4 = (BPS == 4) && ((lo & 3) == 0);
+    const uint8_t* tile = lds + lo;
+
+    // ---- phase 2: per (channel, 16-sample group): transform + plane split ---
+    const uint32_t ngrp = (Tn + 15) >> 4;
+    const uint32_t nitems = g.nch * ngrp;
+    uint32_t mag = 0;
+    for (uint32_t q = tid; q < nitems; q += 256) {
+        const uint32_t grp = q / g.nch;
+        const uint32_t c = q - grp * g.nch;
+        const uint32_t t0 = grp << 4;
+        const uint32_t cnt = min(16u, Tn - t0);
+        uint32_t p1 = 0, p2 = 0;  // p[i-1], p[i-2]
+        uint32_t oprev = 0;       // o[i-1]
+        if (XDELTA) {
+            const int64_t flat = (int64_t)c * g.ns + s0 + t0;
+            if (t0 >= 2) {
+                p1 = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 - 1) * g.nch + c) * BPS, aligned4);
+                p2 = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 - 2) * g.nch + c) * BPS, aligned4);
+            } else {
+                p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
+                p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
+            }
+            oprev = (flat == 0) ? 0u : (p1 - p2 - 128u);  // xor_encode_32 starts from last = 0
+        }
+        uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            if (e < cnt) {
+                uint32_t p = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 + e) * g.nch + c) * BPS, aligned4);
+                uint32_t v;
+                if (XDELTA) {
+                    uint32_t o = p - p1 - 128u;
+                    v = o ^ oprev;
+                    oprev = o;
+                    p1 = p;
+                    // sign-extend from the sample width, fold to a magnitude (escalation test)
+                    int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
+                    mag |= (uint32_t)(x ^ (x >> 31));
+                } else {
+                    v = p;
+                }
+                const uint32_t sh = (e & 3) * 8;
+                pw[0][e >> 2] |= (v & 0xFFu) << sh;
+                pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
+                pw[2][e >> 2] |= ((v >> 16) & 0xFFu) << sh;
+                pw[3][e >> 2] |= (v >> 24) << sh;
+            }
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            uint4 w = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+            *reinterpret_cast<uint4*>(out + (size_t)(k * g.nch + c) * RS + t0) = w;
+        }
+    }
+    if (XDELTA) {
+        mag = wave_or_u32(mag);
+        if (lane_id() == 0 && mag) atomicOr(&needmask[b], mag);
+    }
+    __syncthreads();
+
+    // ---- phase 3: plane rows -> HBM ------------------------------------------
+    const uint32_t upr = ngrp;  // 16-byte units per row
+    const uint32_t nunits = 4 * g.nch * upr;
+    const bool fast = ((g.ns & 15) == 0) && ((s0 & 15) == 0);
+    for (uint32_t u = tid; u < nunits; u += 256) {
+        const uint32_t row = u / upr;  // k*nch + c
+        const uint32_t col = u - row * upr;
+        const uint32_t k = row / g.nch;
+        const uint32_t c = row - k * g.nch;
+        const uint32_t nbytes = min(16u, Tn - col * 16);
+        const uint8_t* sp = out + (size_t)row * RS + col * 16;
+        uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + col * 16;
+        if (fast && nbytes == 16) {
+            *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+        } else {
+            for (uint32_t i = 0; i < nbytes; ++i) dp[i] = sp[i];
+        }
+    }
+}
+
+// planar int32 [nch][ns] (the output of a transform kernel) -> planes, with the
+// optional flat xdelta stage (dct: signal_packer_dct.cpp:117-119; hadamard: none).
+// Element i only needs p[i-1], p[i-2]: no transposition, one thread per 16 elements.
+template <bool XDELTA>
+__global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict__ planar, Geom g, uint32_t nplanes,
+                                                       uint8_t* __restrict__ planes) {
+    const uint32_t b = blockIdx.y;
+    const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 >= g.N) return;
+    const int32_t* p = planar + (size_t)b * g.N;
+    const uint32_t cnt = min(16u, g.N - i0);
+    uint32_t p1 = 0, oprev = 0;
+    if (XDELTA && i0 >= 1) {
+        p1 = (uint32_t)p[i0 - 1];
+        uint32_t p2 = i0 >= 2 ? (uint32_t)p[i0 - 2] : 0u;
+        oprev = p1 - p2 - 128u;
+    }
+    uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (uint32_t e = 0; e < 16; ++e) {
+        if (e < cnt) {
+            uint32_t x = (uint32_t)p[i0 + e];
+            uint32_t v = x;
+            if (XDELTA) {
+                uint32_t o = x - p1 - 128u;
+                v = o ^ oprev;
+                oprev = o;
+                p1 = x;
+            }
+            const uint32_t sh = (e & 3) * 8;
+            pw[0][e >> 2] |= (v & 0xFFu) << sh;
+            pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
+            pw[2][e >> 2] |= ((v >> 16) & 0xFFu) << sh;
+            pw[3][e >> 2] |= (v >> 24) << sh;
+        }
+    }
+    for (uint32_t k = 0; k < nplanes; ++k) {
+        uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + i0;
+        if (cnt == 16) {
+            *reinterpret_cast<uint4*>(dp) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+        } else {
+            for (uint32_t i = 0; i < cnt; ++i) dp[i] = (uint8_t)(pw[k][i >> 2] >> ((i & 3) * 8));
+        }
+    }
+}
+
+// interleaved native -> planar int32 [nch][ns] (front end of the transform packers)
+template <int BPS>
+__global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__ src, Geom g, uint32_t T, int32_t* __restrict__ planar) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t b = blockIdx.y;
+    const uint32_t s0 = blockIdx.x * T;
+    const uint32_t Tn = min(T, g.ns - s0);
+    const uint8_t* blk = src + (size_t)b * g.block_bytes;
+    const uint32_t rowb = g.nch * BPS;
+    const size_t gs = (size_t)s0 * rowb;
+    const uintptr_t abs_s = reinterpret_cast<uintptr_t>(blk) + gs;
+    const uint32_t lo = (uint32_t)(abs_s & 15);
+    const uint8_t* abase = reinterpret_cast<const uint8_t*>(abs_s - lo);
+    const uint32_t span = lo + Tn * rowb;
+    for (uint32_t o = tid * 16; o < span; o += 256 * 16) *reinterpret_cast<uint4*>(lds + o) = *reinterpret_cast<const uint4*>(abase + o);
+    __syncthreads();
+    const bool aligned4 = (BPS == 4) && ((lo & 3) == 0);
+    const uint8_t* tile = lds + lo;
+    // thread <-> (channel row, sample): consecutive lanes write consecutive samples of one channel
+    const uint32_t total = g.nch * Tn;
+    for (uint32_t q = tid; q < total; q += 256) {
+        const uint32_t c = q / Tn, t = q - c * Tn;
+        planar[(size_t)b * g.N + (size_t)c * g.ns + s0 + t] = sample_from_bytes<BPS>(tile + ((size_t)t * g.nch + c) * BPS, aligned4);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// nb bookkeeping (signal_packer_xdelta_hzr.cpp:63-69): nb used by block b =
+// max(nb carried in, need(0..b)); the last value is carried to the next call.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t need_from_mask(uint32_t m) { return m < 0x80u ? 1u : m < 0x8000u ? 2u : m < 0x800000u ? 3u : 4u; }
+
+// single workgroup of 1024 threads; nblocks arbitrary
+__global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ needmask, uint32_t nblocks, uint32_t* __restrict__ nb_state,
+                                                  uint32_t* __restrict__ nbuse, int use_mask) {
+    __shared__ uint32_t wmax[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t lo = tid * per, hi = min(nblocks, lo + per);
+    const uint32_t carry_in = *nb_state;
+    uint32_t m = 0;
+    for (uint32_t b = lo; b < hi; ++b) m = max(m, use_mask ? need_from_mask(needmask[b]) : 0u);
+    // inclusive max-scan over threads
+    uint32_t v = m;
+    const uint32_t l = lane_id(), w = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+        if (l >= (uint32_t)d) v = max(v, o);
+    }
+    if (l == 63) wmax[w] = v;
+    __syncthreads();
+    uint32_t pre = carry_in;
+    for (uint32_t i = 0; i < w; ++i) pre = max(pre, wmax[i]);
+    uint32_t excl = (uint32_t)__shfl_up((int)v, 1, 64);
+    uint32_t run = max(pre, l ? excl : 0u);
+    for (uint32_t b = lo; b < hi; ++b) {
+        run = max(run, use_mask ? need_from_mask(needmask[b]) : 0u);
+        nbuse[b] = run;
+    }
+    __syncthreads();
+    if (tid == 1023) {
+        uint32_t fin = max(pre, v);
+        *nb_state = fin;
+    }
+}
+
+// explicit instantiations used by rspt_hip.cpp
+#define INST_TILE(BPS)                                                                                                   \
+    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*);    \
+    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*);   \
+    template __global__ void k_tile_planar<BPS>(const uint8_t*, Geom, uint32_t, int32_t*);
+INST_TILE(1)
+INST_TILE(2)
+INST_TILE(3)
+INST_TILE(4)
+template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*);
+template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*);
+
+}  // namespace rspt

@@ -1,0 +1,138 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the
+oracle on the same inputs and against the committed golden fixtures.  Bit-exact:
+this is integer / byte work."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import cases
+from streamtools import describe_mismatch, parse_stream
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rspt_amd import api as a
+
+    assert a.lib().rspt_hip_device_count() > 0, "no gfx950 device visible: the HIP path cannot run (no CPU fallback)"
+    return a
+
+
+LOSSLESS = [c["name"] for c in cases.packer_cases() if c["kind"] in ("xdelta_hzr", "hzr")]
+
+
+@pytest.mark.parametrize("name", LOSSLESS)
+def test_lossless_stream_bit_exact(api, orc, golden, packer_cases, name):
+    c, g = packer_cases[name], golden["packers"][name]
+    pk = api.SignalPacker(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    got = pk.compress(c["data"])
+    po = orc.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    want = po.compress(c["data"])
+    assert got == want, describe_mismatch(got, want)
+    assert len(got) == g["size"] and orc.fnv1a(got) == g["fnv1a"] and zlib.crc32(got) == g["crc32"]
+    assert pk.nb == g["final_nb"] == orc.packer_nb(po)
+    dec, used, _ = po.decompress(got)  # the oracle decodes what the GPU wrote
+    assert dec == c["data"].tobytes() and used == len(got)
+    pk.close()
+
+
+@pytest.mark.parametrize("name", sorted(cases.hzr_kat_inputs().keys()))
+def test_hzr_kat_through_hzr_packer(api, orc, golden, name):
+    """raw hzr_encode known answers: plane 0 of a 1-channel 8-bit `hzr` packer
+    IS hzr_encode(data) (signal_packer_base.cpp:69-82)."""
+    data = cases.hzr_kat_inputs()[name]
+    pk = api.new_hzr(1, 1, data.size)
+    got = pk.compress(data, dst_max_len=pk.max_compressed_size)
+    p = parse_stream(got)
+    assert len(p["planes"]) == 4 and p["end"] == len(got)
+    o0 = p["planes"][0]["offset"]
+    chunk0 = got[o0 + 4 : o0 + 4 + p["planes"][0]["len"]]
+    want = orc.hzr_encode(data)
+    assert chunk0 == want, describe_mismatch(b"\0" + struct.pack("<I", len(chunk0)) + chunk0, b"\0" + struct.pack("<I", len(want)) + want)
+    g = golden["hzr"][name]
+    assert len(chunk0) == g["size"] and orc.fnv1a(chunk0) == g["fnv1a"]
+    ok, n = orc.hzr_verify(chunk0)  # every block CRC checks out
+    assert ok and n == data.size
+    pk.close()
+
+
+def test_cxx_factories_drive_the_same_path(api, orc, packer_cases):
+    """include/signal_packer.h: i_signal_packer::new_xdelta_hzr(...)->compress()."""
+    c = packer_cases["readme_sine_xdelta_nb3"]
+    pk = api.CxxSignalPacker("xdelta_hzr", 4, 1, 8192, 3)
+    s = pk.compress(c["data"])
+    assert len(s) == 2028 and orc.fnv1a(s) == 0xF98CEFBD  # SURVEY 6 / README example, current code
+    pk.close()
+
+
+def test_batch_is_sequential_compress_calls(api, orc):
+    """rspt_hip_compress_batch_dev == nblocks successive compress() calls on one
+    instance, including the persistent nb escalation in block order."""
+    import torch
+
+    nch, ns, bps = 3, 1500, 4
+    amps = [10, 10, 1 << 12, 10, 1 << 22, 10, 1 << 30, 10]
+    blocks = [cases._rand_native(nch, ns, bps, 300 + i, a, walk=bool(i & 1)) for i, a in enumerate(amps)]
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 1)
+    want = [po.compress(b) for b in blocks]
+    pk = api.new_xdelta_hzr(bps, nch, ns, 1)
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy()
+    out = d_dst.cpu().numpy()
+    for i in range(len(blocks)):
+        got = out[i, : sizes[i]].tobytes()
+        assert got == want[i], "block %d: %s" % (i, describe_mismatch(got, want[i]))
+    assert pk.nb == orc.packer_nb(po) == 4
+    # a second batch starts from the carried nb
+    d_dst2, d_sizes2 = pk.compress_batch(d_src[:2].contiguous())
+    torch.cuda.synchronize()
+    want2 = [po.compress(b) for b in blocks[:2]]
+    for i in range(2):
+        assert d_dst2[i, : int(d_sizes2[i])].cpu().numpy().tobytes() == want2[i]
+    pk.close()
+
+
+def test_dst_too_small_is_reported(api, packer_cases):
+    c = packer_cases["ecg12x8192_xdelta"]
+    pk = api.new_xdelta_hzr(c["bps"], c["nch"], c["ns"], c["nb"])
+    with pytest.raises(api.RsptHipError) as e:
+        pk.compress(c["data"], dst_max_len=1000)
+    assert e.value.status == -5
+    pk.close()
+
+
+def test_full_size_roundtrip_properties(api, orc):
+    """BASELINE config C3 (64 x 65536 int32), batched: every stream decodes (with
+    the oracle's decoder) to its input, every hzr block CRC verifies, blocks are
+    independent of their batch position."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns, B = 64, 65536, 3
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    d_src = synth.synth_batch_native(B, nch, ns, first_block=7, device="cuda")
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy()
+    po = orc.packer("xdelta_hzr", 4, nch, ns, 3)
+    for b in range(B):
+        s = d_dst[b, : int(sizes[b])].cpu().numpy().tobytes()
+        p = parse_stream(s)
+        assert len(p["planes"]) == 3 and p["end"] == len(s)
+        for pl in p["planes"]:
+            chunk = s[pl["offset"] + 4 : pl["offset"] + 4 + pl["len"]]
+            ok, n = orc.hzr_verify(chunk)
+            assert ok and n == nch * ns
+        dec, used, _ = po.decompress(s)
+        assert used == len(s) and dec == d_src[b].cpu().numpy().tobytes()
+    # position independence: block 1 alone gives the same stream
+    d1, s1 = pk.compress_batch(d_src[1:2].contiguous())
+    torch.cuda.synchronize()
+    assert d1[0, : int(s1[0])].cpu().numpy().tobytes() == d_dst[1, : int(sizes[1])].cpu().numpy().tobytes()
+    pk.close()
