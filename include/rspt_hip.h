@@ -135,6 +135,14 @@ int rspt_hip_stage_count(const rspt_hip_packer* p);
 const char* rspt_hip_stage_name(const rspt_hip_packer* p, int i);
 int rspt_hip_stage_times(rspt_hip_packer* p, float* ms, int n);
 
+/* Test hook: copy a workspace buffer of the LAST batch call to the host
+ * (synchronises).  which: 0 planes [blocks][4][plane_stride] u8, 1 planar
+ * int32 [blocks][N], 2 second int32 buffer (dct), 3 token histograms
+ * [blocks*4*nblk][264] u32, 4 block records [..][4] u32 (mode, payload_len,
+ * tree_bits, fill), 5 nb per block [blocks] u32, 6 means header bytes.
+ * Returns the number of bytes copied (<= cap) or a negative status. */
+long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
-    "rspt_hip_stage_name", "rspt_hip_stage_times",
+    "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read",
 ]
 
 _u8p = C.POINTER(C.c_uint8)
@@ -72,6 +72,7 @@ def lib():
     L.rspt_hip_stage_count.restype, L.rspt_hip_stage_count.argtypes = C.c_int, [C.c_void_p]
     L.rspt_hip_stage_name.restype, L.rspt_hip_stage_name.argtypes = C.c_char_p, [C.c_void_p, C.c_int]
     L.rspt_hip_stage_times.restype, L.rspt_hip_stage_times.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]
+    L.rspt_hip_debug_read.restype, L.rspt_hip_debug_read.argtypes = C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     # the C++ factories behind the same library (include/signal_packer.h), via their C shim
     L.rspt_cxx_new.restype, L.rspt_cxx_new.argtypes = C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
     L.rspt_cxx_delete.restype, L.rspt_cxx_delete.argtypes = None, [C.c_int, C.c_void_p]
@@ -177,6 +178,14 @@ class SignalPacker:
 
     def synchronize(self):
         self._check("rspt_hip_synchronize", self._L.rspt_hip_synchronize(self._h))
+
+    def debug_read(self, which, nbytes):
+        """test hook: workspace buffer `which` of the last batch call (see rspt_hip.h)"""
+        out = np.zeros(nbytes, dtype=np.uint8)
+        n = self._L.rspt_hip_debug_read(self._h, which, out.ctypes.data, nbytes)
+        if n < 0:
+            raise RsptHipError("rspt_hip_debug_read", int(n))
+        return out[:n]
 
     # -- measurement -------------------------------------------------------------
     def set_profiling(self, on=True):

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,7 +100,6 @@ struct rspt_hip_packer {
     size_t cap_blocks = 0;
     uint8_t* planes = nullptr;     // [cap][4][plane_stride]
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
-    double* dscratch = nullptr;    // dct scratch
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
     uint32_t* nb_state = nullptr;  // [1] persistent
@@ -109,7 +109,18 @@ struct rspt_hip_packer {
     BlockMeta* meta = nullptr;     // [..]
     uint64_t* out_off = nullptr;   // [..]
     uint8_t* means = nullptr;      // [cap][hdr_len]
+    int32_t* planar2 = nullptr;    // [cap][N] second int32 buffer (dct output / idct output)
+    uint32_t* txor = nullptr;      // [cap][ntile] decode scans
+    uint32_t* tsum = nullptr;      // [cap][ntile]
+    uint64_t* blk_off = nullptr;   // [cap*4*nblk] decode: hzr block offsets inside each stream
     CrcConsts* crc = nullptr;
+    // dct (signal_packer_dct.cpp:60-74): COS[x][i] and its transpose, built on the host like the reference ctor
+    float* cos_tab = nullptr;
+    float* cos_tab_t = nullptr;
+    double dct_scale0 = 0, dct_scale1 = 0, idct_scale = 0;
+    float dct_cs0 = 0;
+    uint32_t ntile = 0;
+    uint32_t Tn_native = 0;  // tile of k_planar_native
 
     // host API staging
     uint8_t* h_src = nullptr;  // device
@@ -182,7 +193,6 @@ int rspt_hip_device_count(void) {
 static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planes);
     hipFree(p->planar);
-    hipFree(p->dscratch);
     hipFree(p->needmask);
     hipFree(p->nbuse);
     hipFree(p->hist);
@@ -191,9 +201,15 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->meta);
     hipFree(p->out_off);
     hipFree(p->means);
+    hipFree(p->planar2);
+    hipFree(p->txor);
+    hipFree(p->tsum);
+    hipFree(p->blk_off);
+    p->planar2 = nullptr;
+    p->txor = p->tsum = nullptr;
+    p->blk_off = nullptr;
     p->planes = nullptr;
     p->planar = nullptr;
-    p->dscratch = nullptr;
     p->needmask = p->nbuse = p->hist = p->cw = p->tdesc = nullptr;
     p->meta = nullptr;
     p->out_off = nullptr;
@@ -254,6 +270,26 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         p->lds_total = p->in_lds + 4u * g.nch * (T + 16u);
     }
 
+    p->ntile = (g.N + kInvTile - 1) / kInvTile;
+    {
+        // k_planar_native tile: nch rows of (T+1) int32 within 64 KiB
+        uint32_t T = (uint32_t)(65536ull / (4ull * g.nch));
+        T = T > 1 ? T - 1 : 0;
+        if (T > 1024) T = 1024;
+        if (T < 1) {
+            delete p;
+            return RSPT_HIP_ERR_UNSUPPORTED;
+        }
+        p->Tn_native = T;
+    }
+    if (kind == RSPT_HIP_KIND_HADAMARD && ns > 65536) {  // one workgroup transforms one channel in LDS
+        delete p;
+        return RSPT_HIP_ERR_UNSUPPORTED;
+    }
+    if (kind == RSPT_HIP_KIND_DCT && ns > 8192) {  // dense n x n table, as in the reference; FFT path: DESIGN.md
+        delete p;
+        return RSPT_HIP_ERR_UNSUPPORTED;
+    }
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete p;
@@ -272,6 +308,39 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         return RSPT_HIP_ERR_LAUNCH;
     }
     for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&p->ev[i]);
+    if (kind == RSPT_HIP_KIND_DCT) {
+        // init_cos_table (signal_packer_dct.cpp:60-74), host libm, same expression and types
+        const size_t n = ns;
+        std::vector<float> tab(n * n), tabt(n * n);
+        const double PI = 3.14159265358979323846;
+        const double pi_n_2 = PI / ((double)(int)n * 2.0);
+        for (size_t x = 0; x < n; ++x)
+            for (size_t i = 0; i < n; ++i) {
+                const int arg = ((int)x << 1) * (int)i + (int)i;
+                const float v = (float)cos(arg * pi_n_2);
+                tab[x * n + i] = v;
+                tabt[i * n + x] = v;
+            }
+        const double ratio1 = sqrt(2.0 / (double)(int)n);
+        const float cs0 = (float)(1 / sqrt(2));
+        p->dct_cs0 = cs0;
+        p->dct_scale0 = cs0 * ratio1 / 128.0;   // Cs[0]*ratio1/quality (dct.cpp:84)
+        p->dct_scale1 = 1.0f * ratio1 / 128.0;  // Cs[i>0] = 1
+        p->idct_scale = ratio1 * 128.0;          // dct.cpp:97
+        if (hipMalloc(&p->cos_tab, n * n * sizeof(float)) != hipSuccess || hipMalloc(&p->cos_tab_t, n * n * sizeof(float)) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_ALLOC;
+        }
+        if (hipMemcpy(p->cos_tab, tab.data(), n * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->cos_tab_t, tabt.data(), n * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_LAUNCH;
+        }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {  // setup copies ran on the null stream; the handle's stream does not wait for it
+        rspt_hip_packer_destroy(p);
+        return RSPT_HIP_ERR_LAUNCH;
+    }
     *out = p;
     return RSPT_HIP_OK;
 }
@@ -283,6 +352,8 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     free_workspace(p);
     hipFree(p->crc);
     hipFree(p->nb_state);
+    hipFree(p->cos_tab);
+    hipFree(p->cos_tab_t);
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
@@ -322,7 +393,10 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->means, max_blocks * (size_t)(g.hdr_len ? g.hdr_len : 4)) == hipSuccess;
     // planar int32 scratch: transform packers on compress, every packer on decompress
     ok &= hipMalloc(&p->planar, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
-    if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->dscratch, max_blocks * (size_t)g.N * sizeof(double) * 2 + 4096) == hipSuccess;
+    ok &= hipMalloc(&p->txor, max_blocks * (size_t)p->ntile * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->tsum, max_blocks * (size_t)p->ntile * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->blk_off, nhb * sizeof(uint64_t)) == hipSuccess;
+    if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->planar2, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
     if (!ok) {
         free_workspace(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -354,11 +428,14 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     }
     if (g.kind == RSPT_HIP_KIND_HADAMARD) {
         // per channel: mean removal, WHT, truncating /n (signal_packer_hadamard.cpp:57-72)
-        hipLaunchKernelGGL(k_fwht, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means);
+        const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+        hipLaunchKernelGGL((k_fwht<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
         hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes);
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
-        hipLaunchKernelGGL(k_dct, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->dscratch);
-        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 2u, p->planes);
+        hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
+                           p->cos_tab, p->dct_scale0, p->dct_scale1, p->dct_cs0, p->planar2);
+        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes);
     }
     HIPCHK(p, hipGetLastError());
 
@@ -418,6 +495,7 @@ static int ensure_host_staging(rspt_hip_packer* p) {
     if (!p->h_src) {
         if (hipMalloc(&p->h_src, p->g.block_bytes + 64) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
         hipMemset(p->h_src, 0, p->g.block_bytes + 64);
+        hipDeviceSynchronize();  // the memset runs on the null stream; our copies use a non-blocking stream
     }
     if (!p->h_size && hipMalloc(&p->h_size, sizeof(uint64_t)) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
     if (p->h_dst_cap < need_dst) {
@@ -457,8 +535,46 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
     if (rc) return rc;
     HIPCHK(p, hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    launch_decode(p->g, (const uint8_t*)d_src, src_stride, nblocks, p->planes, p->planar, p->nb_state, (uint8_t*)d_dst, d_consumed, p->means,
-                  p->dscratch, st);
+    {
+        const Geom& g = p->g;
+        const uint32_t B = (uint32_t)nblocks;
+        const uint8_t* src = (const uint8_t*)d_src;
+        HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
+        hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
+                           d_consumed, p->means);
+        hipLaunchKernelGGL(k_dec_block, dim3(g.nblk, kMaxPlanes, B), dim3(64), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
+                           d_consumed);
+        const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
+        const dim3 tg(p->ntile, B);
+        if (xd) {
+            hipLaunchKernelGGL((k_inv_tile<0, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_scan_tiles<true>), dim3(B), dim3(1024), 0, st, p->txor, p->ntile);
+            hipLaunchKernelGGL((k_inv_tile<1, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_scan_tiles<false>), dim3(B), dim3(1024), 0, st, p->tsum, p->ntile);
+            hipLaunchKernelGGL((k_inv_tile<2, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+        } else {
+            hipLaunchKernelGGL((k_inv_tile<2, false>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+        }
+        const int32_t* final_planar = p->planar;
+        if (g.kind == RSPT_HIP_KIND_HADAMARD) {
+            const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+            hipLaunchKernelGGL((k_fwht<false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
+        } else if (g.kind == RSPT_HIP_KIND_DCT) {
+            hipLaunchKernelGGL((k_dct<false>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
+                               p->cos_tab_t, 0.0, p->idct_scale, p->dct_cs0, p->planar2);
+            final_planar = p->planar2;
+        }
+        const uint32_t T = min(p->Tn_native, g.ns);
+        const uint32_t lds = g.nch * (T + 1) * 4;
+        const dim3 ng((g.ns + T - 1) / T, B);
+        switch (g.bps) {
+            case 1: hipLaunchKernelGGL((k_planar_native<1>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
+            case 2: hipLaunchKernelGGL((k_planar_native<2>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
+            case 3: hipLaunchKernelGGL((k_planar_native<3>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
+            default: hipLaunchKernelGGL((k_planar_native<4>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
+        }
+    }
     HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
 }
@@ -489,6 +605,29 @@ int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_le
     HIPCHK(p, hipMemcpy(dst_host, p->h_src, p->g.block_bytes, hipMemcpyDeviceToHost));
     *src_len = (size_t)used;
     return RSPT_HIP_OK;
+}
+
+long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, size_t cap) {
+    if (!p || !host_buf || p->cap_blocks == 0) return RSPT_HIP_ERR_ARG;
+    if (hipSetDevice(p->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return RSPT_HIP_ERR_LAUNCH;
+    const Geom& g = p->g;
+    const size_t nhb = p->cap_blocks * kMaxPlanes * g.nblk;
+    const void* src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: src = p->planes; n = p->cap_blocks * kMaxPlanes * g.plane_stride; break;
+        case 1: src = p->planar; n = p->cap_blocks * (size_t)g.N * 4; break;
+        case 2: src = p->planar2; n = p->planar2 ? p->cap_blocks * (size_t)g.N * 4 : 0; break;
+        case 3: src = p->hist; n = nhb * kSymStride * 4; break;
+        case 4: src = p->meta; n = nhb * sizeof(BlockMeta); break;
+        case 5: src = p->nbuse; n = p->cap_blocks * 4; break;
+        case 6: src = p->means; n = p->cap_blocks * (size_t)g.hdr_len; break;
+        default: return RSPT_HIP_ERR_ARG;
+    }
+    if (!src || n == 0) return 0;
+    if (n > cap) n = cap;
+    if (hipMemcpy(host_buf, src, n, hipMemcpyDeviceToHost) != hipSuccess) return RSPT_HIP_ERR_LAUNCH;
+    return (long long)n;
 }
 
 int rspt_hip_set_profiling(rspt_hip_packer* p, int on) {
