@@ -40,10 +40,10 @@ struct Geom {
 
 // CRC-32C constants for the parallel checksum (tools/kernel_model.py:crc_parallel).
 struct CrcConsts {
-    uint32_t table[256];      // byte-at-a-time LUT, reflected poly 0x82F63B78 (hzr_crc32c.c:32)
-    uint32_t lane_shift[64];  // x^(128*(63-l))
-    uint32_t wave_shift[16];  // x^(8*1024*(15-w))
-    uint32_t row_shift;       // x^(8*16384)
+    uint32_t table[4][256];   // slice-by-4 LUTs, reflected poly 0x82F63B78; table[0] = hzr_crc32c.c:32
+    uint32_t lane_shift[64];  // x^(8*64*(63-l)): a lane's 64-byte chunk to the end of its wave's 4 KiB slot
+    uint32_t wave_shift[16];  // x^(8*4096*(15-w)): a wave's slot to the end of the 64 KiB window
+    uint32_t big_shift;       // x^(8*65536): the one chunk that can lie in front of the window
     uint32_t prefix;          // 4 bytes X (LE) with raw_crc(X) = 0xFFFFFFFF
     uint32_t pad[2];
 };
@@ -189,30 +189,34 @@ __device__ __forceinline__ uint32_t run_extra_value(uint32_t sym, uint32_t z) {
     return sym == 257 ? z - 3 : sym == 258 ? z - 7 : sym == 259 ? z - 23 : sym == 260 ? z - 279 : 0u;
 }
 
-// Walk the tokens that START in granule g.  zb = zeros immediately before the
-// granule, za = zeros immediately after it (tools/kernel_model.py:granule_tokens).
-// f(sym, run_length) is called once per token in stream order.
-template <typename F>
-__device__ __forceinline__ void granule_for_each_token(const Granule& g, uint32_t zb, uint32_t za, F&& f) {
-    uint32_t dist = zb;
-#pragma unroll
-    for (uint32_t i = 0; i < 16; ++i) {
-        if (i < g.nv) {
-            uint32_t x = granule_byte(g, i);
-            if (x != 0) {
-                f(x, 0u);
-                dist = 0;
-            } else {
-                if (dist == 0 || dist == kRunCap || dist == 2 * kRunCap || dist == 3 * kRunCap) {
-                    uint32_t ahead = (uint32_t)__builtin_ctz(~(g.zm >> i) | (1u << (g.nv - i)));
-                    uint32_t rem = ahead + ((i + ahead == g.nv) ? za : 0u);
-                    uint32_t z = rem < kRunCap ? rem : kRunCap;
-                    f(run_symbol(z), z);
-                }
-                ++dist;
-            }
-        }
+// Token positions of a granule as bit masks (tools/kernel_model.py:granule_masks):
+//   lits    valid non-zero bytes: one literal token each
+//   starts  zero bytes at which a zero-run token starts: a zero whose distance
+//           from its run start is a multiple of 16662 (hzr_encode.c:149,417)
+struct GranuleMasks {
+    uint32_t lits, starts;
+};
+
+__device__ __forceinline__ GranuleMasks granule_masks(uint32_t zm, uint32_t nv, uint32_t zb) {
+    GranuleMasks m;
+    const uint32_t valid = (1u << nv) - 1u;
+    m.lits = ~zm & valid;
+    m.starts = zm & ~(zm << 1) & ~1u;  // interior runs: the byte before is non-zero
+    const uint32_t lead = (uint32_t)__builtin_ctz(~zm | (1u << nv));
+    if (lead) {  // the leading zeros continue a run of zb zeros (zb = 0: a run starts at byte 0)
+        const uint32_t q = (zb >= kRunCap) + (zb >= 2 * kRunCap) + (zb >= 3 * kRunCap);
+        const uint32_t r = zb - q * kRunCap;
+        const uint32_t icap = r ? kRunCap - r : 0u;
+        if (icap < lead) m.starts |= 1u << icap;
     }
+    return m;
+}
+
+// length of the run token that starts at byte i of the granule
+__device__ __forceinline__ uint32_t run_token_length(uint32_t zm, uint32_t nv, uint32_t za, uint32_t i) {
+    const uint32_t ahead = (uint32_t)__builtin_ctz(~(zm >> i) | (1u << (nv - i)));
+    const uint32_t rem = ahead + ((i + ahead == nv) ? za : 0u);
+    return rem < kRunCap ? rem : kRunCap;
 }
 
 // ---------------------------------------------------------------------------

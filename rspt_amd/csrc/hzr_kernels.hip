@@ -89,24 +89,57 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
 // ===========================================================================
 // k_hist
 // ===========================================================================
+// literals at static byte positions (predicated LDS atomics), then the few run
+// tokens by iterating over the `starts` mask.  The callers walk a lane's four
+// granules with a rolled loop that rotates them through one register set, so the
+// body exists once (instruction-cache footprint) and still uses ds_ instructions.
+struct GranuleRegs {
+    uint32_t w0, w1, w2, w3, nv, zm, zb, za;
+};
+__device__ __forceinline__ GranuleRegs granule_regs(const LaneBlock& L, int r) {
+    return GranuleRegs{L.g[r].w[0], L.g[r].w[1], L.g[r].w[2], L.g[r].w[3], L.g[r].nv, L.g[r].zm, L.zb[r], L.za[r]};
+}
+__device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
+                                          uint32_t za, uint32_t* s_hist) {
+    const GranuleMasks m = granule_masks(zm, nv, zb);
+    const uint32_t w[4] = {w0, w1, w2, w3};
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        if ((m.lits >> i) & 1u) atomicAdd(&s_hist[x], 1u);
+    }
+    uint32_t st = m.starts;
+    while (st) {
+        const uint32_t i = (uint32_t)__builtin_ctz(st);
+        st &= st - 1;
+        atomicAdd(&s_hist[run_symbol(run_token_length(zm, nv, za, i))], 1u);
+    }
+}
+
 __global__ __launch_bounds__(kEncThreads) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                     uint32_t* __restrict__ hist) {
+                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_hist[kSymStride];
     __shared__ uint32_t s_scr[2 * kEncWaves];
     const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
     if (k >= nbuse[b]) return;
+    const uint32_t hb = hb_index(g, b, k, j);
+    if (!nzflag[hb]) return;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
     const uint32_t tid = threadIdx.x;
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     if (tid < kSymStride) s_hist[tid] = 0;
     LaneBlock L;
     load_and_chain(in, in_size, L, s_scr);  // contains the barrier that publishes the zeroed histogram
-#pragma unroll
+    GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
+#pragma unroll 1
     for (int r = 0; r < 4; ++r) {
-        granule_for_each_token(L.g[r], L.zb[r], L.za[r], [&](uint32_t sym, uint32_t) { atomicAdd(&s_hist[sym], 1u); });
+        hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
+        q0 = q1;
+        q1 = q2;
+        q2 = q3;
     }
     __syncthreads();
-    if (tid < kSymStride) hist[(size_t)hb_index(g, b, k, j) * kSymStride + tid] = s_hist[tid];
+    if (tid < kSymStride) hist[(size_t)hb * kSymStride + tid] = s_hist[tid];
 }
 
 // ===========================================================================
@@ -162,8 +195,8 @@ __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
 }
 
 __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, Geom g, const uint32_t* __restrict__ nbuse,
-                                                         uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
-                                                         BlockMeta* __restrict__ meta) {
+                                                         const uint32_t* __restrict__ nzflag, uint32_t nhb_total, uint32_t* __restrict__ cw,
+                                                         uint32_t* __restrict__ tdesc, BlockMeta* __restrict__ meta) {
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
@@ -173,6 +206,10 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     TreeLds& t = s_t[wv];
     if (k >= nbuse[b]) {
         if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
+        return;
+    }
+    if (!nzflag[hb]) {  // all-zero block (flagged by the front end): EncodeFill with value 0
+        if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
         return;
     }
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
@@ -342,11 +379,27 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
 // ===========================================================================
 // k_encode
 // ===========================================================================
+// The payload image lives in LDS with one pad word after every 16 words, so
+// that both access patterns are bank-conflict free: consecutive words by
+// consecutive lanes (emit, copy-out) and one 64-byte chunk per lane (CRC).
+__device__ __forceinline__ uint32_t skew(uint32_t w) { return w + (w >> 4); }
+constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logical words (payload + read slack)
+constexpr uint32_t kStagePhys = kStageWords + (kStageWords >> 4) + 2;   // physical words
+
+struct EncLds {
+    uint32_t stage[kStagePhys];
+    uint32_t cw[kSymStride];
+    uint32_t crc[4][256];
+    uint32_t scr[2 * kEncWaves];
+    uint32_t wsum[kEncWaves];
+    uint32_t crc_out;
+};
+
 struct BitSink {
     uint32_t* stage;
     uint64_t acc;
-    uint32_t n;     // bits held in acc
-    uint32_t word;  // next staging word
+    uint32_t n;     // bits held in acc (< 32 between calls)
+    uint32_t word;  // next logical staging word
     __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
         stage = s;
         acc = 0;
@@ -357,35 +410,98 @@ struct BitSink {
         acc |= (uint64_t)v << n;
         n += len;
         if (n >= 32) {
-            atomicOr(&stage[word++], (uint32_t)acc);
+            atomicOr(&stage[skew(word)], (uint32_t)acc);
+            ++word;
             acc >>= 32;
             n -= 32;
         }
     }
     __device__ __forceinline__ void flush() {
-        if (n) atomicOr(&stage[word], (uint32_t)acc);
+        if (n) atomicOr(&stage[skew(word)], (uint32_t)acc);
     }
 };
 
-// message byte p of the virtual CRC input V = X || payload, payload coordinates
-// (p in [-4,0) addresses the 4 prefix bytes X, p < -4 is the zero front padding)
-__device__ __forceinline__ uint32_t vmsg_byte(const uint8_t* stage, int32_t p, uint32_t prefix) {
-    if (p >= 0) return stage[p];
+// pass 1: number of stream bits of the tokens that start in this granule
+__device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
+                                              uint32_t za, const uint32_t* s_cw) {
+    const GranuleMasks m = granule_masks(zm, nv, zb);
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    uint32_t nb = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        if ((m.lits >> i) & 1u) nb += s_cw[x] >> 24;
+    }
+    uint32_t st = m.starts;
+    while (st) {
+        const uint32_t i = (uint32_t)__builtin_ctz(st);
+        st &= st - 1;
+        const uint32_t sym = run_symbol(run_token_length(zm, nv, za, i));
+        nb += (s_cw[sym] >> 24) + run_extra_bits(sym);
+    }
+    return nb;
+}
+
+// pass 2: emit the codes of this granule's tokens at stream bit `bitpos` (hzr_encode.c:410-457)
+__device__ __forceinline__ void emit_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
+                                          const uint32_t* s_cw, uint32_t* stage, uint32_t bitpos) {
+    const GranuleMasks m = granule_masks(zm, nv, zb);
+    const uint32_t w[4] = {w0, w1, w2, w3};
+    BitSink sink;
+    sink.start(stage, bitpos);
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        if ((m.lits >> i) & 1u) {
+            const uint32_t c = s_cw[x];
+            sink.put(c & 0x00FFFFFFu, c >> 24);
+        } else if ((m.starts >> i) & 1u) {
+            const uint32_t z = run_token_length(zm, nv, za, i);
+            const uint32_t sym = run_symbol(z);
+            const uint32_t c = s_cw[sym];
+            sink.put(c & 0x00FFFFFFu, c >> 24);           // code first ...
+            const uint32_t eb = run_extra_bits(sym);
+            if (eb) sink.put(run_extra_value(sym, z), eb);  // ... then the run's extra bits
+        }
+    }
+    sink.flush();
+}
+
+// byte p of the virtual CRC input V = X || payload, in payload coordinates
+// (p in [-4,0) addresses the prefix X, p < -4 the zero front padding)
+__device__ __forceinline__ uint32_t vmsg_byte(const uint32_t* stage, int32_t p, uint32_t prefix) {
+    if (p >= 0) return (stage[skew((uint32_t)p >> 2)] >> (((uint32_t)p & 3u) * 8)) & 0xFFu;
     if (p >= -4) return (prefix >> ((p + 4) * 8)) & 0xFFu;
     return 0;
 }
 
-__global__ __launch_bounds__(kEncThreads) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+// raw CRC state (from 0) after the 64 bytes [lo, lo+64) of V
+__device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo, uint32_t L, uint32_t prefix) {
+    uint32_t c = 0;
+    if (lo >= 0) {
+        const uint32_t a = (uint32_t)lo >> 2, sh = (uint32_t)lo & 3u;
+        uint32_t prev = d.stage[skew(a)];
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) {
+            const uint32_t next = d.stage[skew(a + q + 1)];
+            c ^= __builtin_amdgcn_alignbyte(next, prev, sh);
+            prev = next;
+            c = d.crc[3][c & 0xFFu] ^ d.crc[2][(c >> 8) & 0xFFu] ^ d.crc[1][(c >> 16) & 0xFFu] ^ d.crc[0][c >> 24];
+        }
+    } else {
+        for (int32_t p = lo; p < lo + 64; ++p) {
+            c ^= vmsg_byte(d.stage, p, prefix);
+            c = (c >> 8) ^ d.crc[0][c & 0xFFu];
+        }
+    }
+    return c;
+}
+
+__global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
                                                        const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                        const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                        const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_stage[kHzrBlock / 4 + 8];
-    __shared__ uint32_t s_cw[kSymStride];
-    __shared__ uint32_t s_crctab[256];
-    __shared__ uint32_t s_scr[2 * kEncWaves];
-    __shared__ uint32_t s_wsum[kEncWaves];
-    __shared__ uint32_t s_crc;
-
+    __shared__ EncLds d;
     const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
     if (k >= nbuse[b]) return;
     const uint32_t hb = hb_index(g, b, k, j);
@@ -393,132 +509,126 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(const uint8_t* __restric
     if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const BlockMeta m = meta[hb];
+    uint8_t* o = dst + (size_t)b * dst_stride + off;
+
+    if (m.mode == kModeFill) {  // EncodeFill (hzr_encode.c:341-367): [00 00][crc32c(value)][02][value]
+        if (tid == 0) {
+            uint32_t c = 0xFFFFFFFFu ^ m.fill;
+            c = ~((c >> 8) ^ cc->table[0][c & 0xFFu]);
+            o[0] = 0;
+            o[1] = 0;
+            o[2] = (uint8_t)c;
+            o[3] = (uint8_t)(c >> 8);
+            o[4] = (uint8_t)(c >> 16);
+            o[5] = (uint8_t)(c >> 24);
+            o[6] = (uint8_t)kModeFill;
+            o[7] = (uint8_t)m.fill;
+        }
+        return;
+    }
+
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-    uint8_t* stage8 = reinterpret_cast<uint8_t*>(s_stage);
     const uint32_t L = m.payload_len;
-
-    if (tid < 256) s_crctab[tid] = cc->table[tid];
+    {
+        const uint32_t* t = &cc->table[0][0];
+        uint32_t* dt = &d.crc[0][0];
+        dt[tid] = t[tid];  // 1024 threads, 4 x 256 entries
+    }
 
     if (m.mode == kModeHuff) {
-        // zero the payload image (bits are OR-ed in)
-        for (uint32_t i = tid; i < kHzrBlock / 16 + 2; i += kEncThreads) reinterpret_cast<uint4*>(s_stage)[i] = make_uint4(0, 0, 0, 0);
-        if (tid < kSymStride) s_cw[tid] = cw[(size_t)hb * kSymStride + tid];
+        // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
+        const uint32_t zwords = skew((L >> 2) + 24);
+        for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+        if (tid < kSymStride) d.cw[tid] = cw[(size_t)hb * kSymStride + tid];
         LaneBlock B;
-        load_and_chain(in, in_size, B, s_scr);  // barriers inside publish s_cw and the zeroed image
-        // tree description (hzr_encode.c:177-219)
-        const uint32_t twords = (m.tree_bits + 31) >> 5;
-        if (tid < twords) atomicOr(&s_stage[tid], tdesc[(size_t)hb * kTdescWords + tid]);
-        // pass 1: bits per granule
-        uint32_t nbits[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uint32_t nb_ = 0;
-            granule_for_each_token(B.g[r], B.zb[r], B.za[r], [&](uint32_t sym, uint32_t) { nb_ += (s_cw[sym] >> 24) + run_extra_bits(sym); });
-            nbits[r] = nb_;
+        load_and_chain(in, in_size, B, d.scr);  // barriers inside publish cw and the zeroed image
+        const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219)
+        if (tid < twords) atomicOr(&d.stage[skew(tid)], tdesc[(size_t)hb * kTdescWords + tid]);
+        GranuleRegs q0 = granule_regs(B, 0), q1 = granule_regs(B, 1), q2 = granule_regs(B, 2), q3 = granule_regs(B, 3);
+        uint32_t nbits[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {  // rolled: granules and results rotate through fixed registers
+            const uint32_t nbv = bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw);
+            const GranuleRegs t = q0;
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            q3 = t;
+            nbits[0] = nbits[1];
+            nbits[1] = nbits[2];
+            nbits[2] = nbits[3];
+            nbits[3] = nbv;
         }
         // exclusive bit offsets in byte order: wave w rows 0..3, lanes 0..63
         uint32_t excl[4];
         uint32_t run = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            uint32_t inc = wave_scan_add(nbits[r]);
+            const uint32_t inc = wave_scan_add(nbits[r]);
             excl[r] = run + inc - nbits[r];
             run += (uint32_t)__shfl((int)inc, 63, 64);
         }
-        if (l == 0) s_wsum[w] = run;
+        if (l == 0) d.wsum[w] = run;
         __syncthreads();
         uint32_t wbase = m.tree_bits;
-        for (uint32_t i = 0; i < w; ++i) wbase += s_wsum[i];
-        // pass 2: emit (hzr_encode.c:410-457); code first, then the run's extra bits
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (nbits[r]) {
-                BitSink sink;
-                sink.start(s_stage, wbase + excl[r]);
-                granule_for_each_token(B.g[r], B.zb[r], B.za[r], [&](uint32_t sym, uint32_t z) {
-                    const uint32_t c = s_cw[sym];
-                    sink.put(c & 0x00FFFFFFu, c >> 24);
-                    const uint32_t eb = run_extra_bits(sym);
-                    if (eb) sink.put(run_extra_value(sym, z), eb);
-                });
-                sink.flush();
-            }
+        for (uint32_t i = 0; i < w; ++i) wbase += d.wsum[i];
+        uint32_t pos0 = wbase + excl[0], pos1 = wbase + excl[1], pos2 = wbase + excl[2], pos3 = wbase + excl[3];
+        uint32_t nz0 = nbits[0], nz1 = nbits[1], nz2 = nbits[2], nz3 = nbits[3];
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {  // after four rotations q0..q3 are back in order
+            if (nz0) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw, d.stage, pos0);
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+            pos0 = pos1;
+            pos1 = pos2;
+            pos2 = pos3;
+            nz0 = nz1;
+            nz1 = nz2;
+            nz2 = nz3;
         }
-    } else if (m.mode == kModeCopy) {
-        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block
-        for (uint32_t i = tid; i < kHzrBlock / 16; i += kEncThreads) {
+    } else {
+        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
+        for (uint32_t gi = tid; gi < kStageWords / 4; gi += kEncThreads) {
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (i * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)i * 16);
-            reinterpret_cast<uint4*>(s_stage)[i] = v;
+            if (gi * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)gi * 16);
+            const uint32_t p = skew(gi * 4);  // the 4 words of a granule stay adjacent under the skew
+            d.stage[p] = v.x;
+            d.stage[p + 1] = v.y;
+            d.stage[p + 2] = v.z;
+            d.stage[p + 3] = v.w;
         }
-    } else {  // Fill (hzr_encode.c:341-367): payload = the fill byte
-        if (tid == 0) s_stage[0] = m.fill;
     }
     __syncthreads();
 
-    // ---- CRC-32C of payload bytes [0, L) (tools/kernel_model.py:crc_parallel) ----
+    // ---- CRC-32C of payload bytes [0, L): virtual message V = X || payload, cut into
+    //      64-byte chunks counted from its END; lane tid owns chunk (1023 - tid) --------
     {
-        const uint32_t Lv = L + 4;
-        const uint32_t G = (Lv + 15) >> 4;
-        const uint32_t rows = (G + kEncThreads - 1) / kEncThreads;
-        const uint32_t lane_k = cc->lane_shift[l];
-        const uint32_t row_k = cc->row_shift;
         const uint32_t prefix = cc->prefix;
-        const uint32_t sh = L & 3u;  // every granule starts at L (mod 16): one byte shift for all lanes
-        uint32_t acc = 0;
-        for (int rowE = (int)rows - 1; rowE >= 0; --rowE) {
-            const uint32_t ge = (uint32_t)rowE * kEncThreads + (kEncThreads - 1 - tid);
-            const int32_t hi = (int32_t)L - (int32_t)(16 * ge);  // exclusive end, payload coordinates
-            const int32_t lo = hi - 16;
-            uint32_t c = 0;
-            if (hi > -4) {
-                uint32_t d[4];
-                if (lo >= 0) {
-                    const uint32_t a = (uint32_t)lo >> 2;
-                    uint32_t x0 = s_stage[a], x1 = s_stage[a + 1], x2 = s_stage[a + 2], x3 = s_stage[a + 3];
-                    uint32_t x4 = sh ? s_stage[a + 4] : 0u;
-                    d[0] = __builtin_amdgcn_alignbyte(x1, x0, sh);
-                    d[1] = __builtin_amdgcn_alignbyte(x2, x1, sh);
-                    d[2] = __builtin_amdgcn_alignbyte(x3, x2, sh);
-                    d[3] = __builtin_amdgcn_alignbyte(x4, x3, sh);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t v = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v |= vmsg_byte(stage8, lo + q * 4 + e, prefix) << (8 * e);
-                        d[q] = v;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    c ^= d[q];
-                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
-                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
-                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
-                    c = (c >> 8) ^ s_crctab[c & 0xFFu];
-                }
-            }
-            const unsigned long long any = __ballot(c != 0);
-            uint32_t red = 0;
-            if (any) red = wave_xor_u32(gf_mul(c, lane_k));
-            acc = gf_mul(acc, row_k) ^ red;
+        const int32_t hi = (int32_t)L - 64 * (int32_t)(kEncThreads - 1 - tid);
+        uint32_t c = 0;
+        if (hi > -4) c = crc_chunk64(d, hi - 64, L, prefix);
+        uint32_t red = 0;
+        if (__ballot(c != 0)) red = wave_xor_u32(gf_mul(c, cc->lane_shift[l]));
+        if (l == 0) {
+            uint32_t v = gf_mul(red, cc->wave_shift[w]);
+            // the only chunk that can precede the 64 KiB window (L + 4 > 65536): X and up to 3 payload bytes
+            if (w == 0 && L + 4 > kHzrBlock) v ^= gf_mul(crc_chunk64(d, (int32_t)L - 64 * (int32_t)kEncThreads - 64, L, prefix), cc->big_shift);
+            d.wsum[w] = v;
         }
-        if (l == 0) s_wsum[w] = gf_mul(acc, cc->wave_shift[w]);
         __syncthreads();
         if (tid == 0) {
             uint32_t t = 0;
-            for (int i = 0; i < kEncWaves; ++i) t ^= s_wsum[i];
-            s_crc = ~t;
+            for (int i = 0; i < kEncWaves; ++i) t ^= d.wsum[i];
+            d.crc_out = ~t;
         }
         __syncthreads();
     }
 
     // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
-    uint8_t* o = dst + (size_t)b * dst_stride + off;
     if (tid == 0) {
-        const uint32_t crc = s_crc;
+        const uint32_t crc = d.crc_out;
         o[0] = (uint8_t)(L - 1);
         o[1] = (uint8_t)((L - 1) >> 8);
         o[2] = (uint8_t)crc;
@@ -531,13 +641,12 @@ __global__ __launch_bounds__(kEncThreads) void k_encode(const uint8_t* __restric
     const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
     const uint32_t nd = (L - head) >> 2;
     const uint32_t tail = L - head - 4 * nd;
-    if (tid < head) po[tid] = stage8[tid];
-    if (tid < tail) po[head + 4 * nd + tid] = stage8[head + 4 * nd + tid];
+    if (tid < head) po[tid] = (uint8_t)vmsg_byte(d.stage, (int32_t)tid, 0);
+    if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)vmsg_byte(d.stage, (int32_t)(head + 4 * nd + tid), 0);
     uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
     for (uint32_t i = tid; i < nd; i += kEncThreads) {
-        // staging bytes [head+4i, head+4i+4): unaligned in LDS by (head & 3)
-        const uint32_t x0 = s_stage[i], x1 = s_stage[i + 1];
-        pw[i] = __builtin_amdgcn_alignbyte(x1, x0, head);
+        // payload bytes [head+4i, head+4i+4): off the LDS word grid by (head & 3)
+        pw[i] = __builtin_amdgcn_alignbyte(d.stage[skew(i + 1)], d.stage[skew(i)], head);
     }
 }
 

@@ -52,7 +52,8 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
 // LDS: [ in tile: T*nch*BPS + 16 ][ out: NPLANES*nch rows of (T+16) bytes ]
 template <int BPS, bool XDELTA>
 __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t in_lds_bytes,
-                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask) {
+                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
+                                                     uint32_t* __restrict__ nzflag) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.y;
@@ -72,10 +73,14 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
         uint4 v = *reinterpret_cast<const uint4*>(abase + o);
         *reinterpret_cast<uint4*>(lds + o) = v;
     }
-    __syncthreads();
-
     uint8_t* out = lds + in_lds_bytes;
     const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
+    // "this hzr block holds a non-zero byte" flags, first setter in the workgroup forwards to HBM.
+    // A tile row (<= 8192 samples) touches at most two hzr blocks: [rel][plane][channel].
+    uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)4 * g.nch * RS);
+    for (uint32_t i = tid; i < 8 * g.nch; i += 256) s_nz[i] = 0;
+    __syncthreads();
+
     const bool aligned4 = (BPS == 4) && ((lo & 3) == 0);
     const uint8_t* tile = lds + lo;
 
@@ -125,10 +130,17 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
                 pw[3][e >> 2] |= (v >> 24) << sh;
             }
         }
+        const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
+        const uint32_t jb = (c * g.ns + s0) >> 16;
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             uint4 w = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
             *reinterpret_cast<uint4*>(out + (size_t)(k * g.nch + c) * RS + t0) = w;
+            if (w.x | w.y | w.z | w.w) {
+                const uint32_t ja = f0 >> 16, jz = f1 >> 16;
+                if (atomicOr(&s_nz[((ja - jb) * 4 + k) * g.nch + c], 1u) == 0) atomicOr(&nzflag[hb_index(g, b, k, ja)], 1u);
+                if (jz != ja && atomicOr(&s_nz[((jz - jb) * 4 + k) * g.nch + c], 1u) == 0) atomicOr(&nzflag[hb_index(g, b, k, jz)], 1u);
+            }
         }
     }
     if (XDELTA) {
@@ -162,10 +174,10 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
 // Element i only needs p[i-1], p[i-2]: no transposition, one thread per 16 elements.
 template <bool XDELTA>
 __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict__ planar, Geom g, uint32_t nplanes,
-                                                       uint8_t* __restrict__ planes) {
+                                                       uint8_t* __restrict__ planes, uint32_t* __restrict__ nzflag) {
     const uint32_t b = blockIdx.y;
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 16;
-    if (i0 >= g.N) return;
+    if (i0 >= g.N) return;  // (a wave's 1024 elements never straddle a 64 KiB hzr block)
     const int32_t* p = planar + (size_t)b * g.N;
     const uint32_t cnt = min(16u, g.N - i0);
     uint32_t p1 = 0, oprev = 0;
@@ -194,6 +206,9 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
         }
     }
     for (uint32_t k = 0; k < nplanes; ++k) {
+        const bool nz = (pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0;
+        const unsigned long long any = __ballot(nz);
+        if (any && lane_id() == (uint32_t)__builtin_ctzll(__ballot(1))) atomicOr(&nzflag[hb_index(g, b, k, i0 >> 16)], 1u);
         uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + i0;
         if (cnt == 16) {
             *reinterpret_cast<uint4*>(dp) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
@@ -273,14 +288,14 @@ __global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ n
 
 // explicit instantiations used by rspt_hip.cpp
 #define INST_TILE(BPS)                                                                                                   \
-    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*);    \
-    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*);   \
+    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*);    \
+    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*);   \
     template __global__ void k_tile_planar<BPS>(const uint8_t*, Geom, uint32_t, int32_t*);
 INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
-template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*);
-template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*);
+template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
+template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 
 }  // namespace rspt

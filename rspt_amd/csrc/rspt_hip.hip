@@ -49,11 +49,13 @@ void make_crc_consts(CrcConsts& cc) {
     for (uint32_t b = 0; b < 256; ++b) {
         uint32_t r = b;
         for (int k = 0; k < 8; ++k) r = (r >> 1) ^ (kCrcPoly & (0u - (r & 1u)));
-        cc.table[b] = r;
+        cc.table[0][b] = r;
     }
-    for (int l = 0; l < 64; ++l) cc.lane_shift[l] = x_pow_bytes(16ull * (63 - l));
-    for (int w = 0; w < 16; ++w) cc.wave_shift[w] = x_pow_bytes(1024ull * (15 - w));
-    cc.row_shift = x_pow_bytes(16384);
+    for (int t = 1; t < 4; ++t)  // slice-by-4: table[t][b] = state after byte b followed by t zero bytes
+        for (uint32_t b = 0; b < 256; ++b) cc.table[t][b] = (cc.table[t - 1][b] >> 8) ^ cc.table[0][cc.table[t - 1][b] & 0xFFu];
+    for (int l = 0; l < 64; ++l) cc.lane_shift[l] = x_pow_bytes(64ull * (63 - l));
+    for (int w = 0; w < 16; ++w) cc.wave_shift[w] = x_pow_bytes(4096ull * (15 - w));
+    cc.big_shift = x_pow_bytes(65536);
     // X with raw_crc(X) = 0xFFFFFFFF: the 4-byte raw CRC map is linear and invertible
     uint32_t img[32];
     for (int b = 0; b < 32; ++b) img[b] = raw_crc4(1u << b);
@@ -102,6 +104,7 @@ struct rspt_hip_packer {
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
+    uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte
     uint32_t* nb_state = nullptr;  // [1] persistent
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
     uint32_t* cw = nullptr;        // same
@@ -156,10 +159,10 @@ static void launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nblock
     dim3 grid((g.ns + p->T - 1) / p->T, (unsigned)nblocks);
     if (g.kind == RSPT_HIP_KIND_XDELTA_HZR) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_total);
-        hipLaunchKernelGGL((k_tile_planes<BPS, true>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask);
+        hipLaunchKernelGGL((k_tile_planes<BPS, true>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask, p->nzflag);
     } else if (g.kind == RSPT_HIP_KIND_HZR) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_total);
-        hipLaunchKernelGGL((k_tile_planes<BPS, false>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask);
+        hipLaunchKernelGGL((k_tile_planes<BPS, false>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask, p->nzflag);
     } else {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planar<BPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->in_lds);
         hipLaunchKernelGGL((k_tile_planar<BPS>), grid, dim3(256), p->in_lds, st, d_src, g, p->T, p->planar);
@@ -195,6 +198,8 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planar);
     hipFree(p->needmask);
     hipFree(p->nbuse);
+    hipFree(p->nzflag);
+    p->nzflag = nullptr;
     hipFree(p->hist);
     hipFree(p->cw);
     hipFree(p->tdesc);
@@ -251,7 +256,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     {
         const uint64_t rowb = (uint64_t)g.nch * g.bps;
         auto fit = [&](uint64_t budget) -> uint32_t {
-            const uint64_t fixed = 32 + 64ull * g.nch;
+            const uint64_t fixed = 32 + 64ull * g.nch + 32ull * g.nch;  // slack + row pads + nz flags
             if (budget <= fixed) return 0;
             uint64_t t = (budget - fixed) / (rowb + 4ull * g.nch);
             t &= ~15ull;
@@ -267,7 +272,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         if (T > ns16) T = ns16;
         p->T = T;
         p->in_lds = (uint32_t)(((uint64_t)T * rowb + 16 + 15) & ~15ull);
-        p->lds_total = p->in_lds + 4u * g.nch * (T + 16u);
+        p->lds_total = p->in_lds + 4u * g.nch * (T + 16u) + 32u * g.nch;
     }
 
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
@@ -385,6 +390,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->planes, max_blocks * kMaxPlanes * g.plane_stride + 4096) == hipSuccess;
     ok &= hipMalloc(&p->needmask, max_blocks * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->nzflag, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->cw, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->tdesc, nhb * kTdescWords * sizeof(uint32_t)) == hipSuccess;
@@ -420,6 +426,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_PRE, st);
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     if (xd) HIPCHK(p, hipMemsetAsync(p->needmask, 0, nblocks * sizeof(uint32_t), st));
+    HIPCHK(p, hipMemsetAsync(p->nzflag, 0, nblocks * kMaxPlanes * g.nblk * sizeof(uint32_t), st));
     switch (g.bps) {
         case 1: launch_front<1>(p, src, nblocks, st); break;
         case 2: launch_front<2>(p, src, nblocks, st); break;
@@ -431,11 +438,11 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
         hipLaunchKernelGGL((k_fwht<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
-        hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes);
+        hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
         hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
                            p->cos_tab, p->dct_scale0, p->dct_scale1, p->dct_cs0, p->planar2);
-        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes);
+        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes, p->nzflag);
     }
     HIPCHK(p, hipGetLastError());
 
@@ -443,11 +450,11 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     hipLaunchKernelGGL(k_nb_scan, dim3(1), dim3(1024), 0, st, p->needmask, B, p->nb_state, p->nbuse, xd ? 1 : 0);
 
     stamp(p, ST_HIST, st);
-    hipLaunchKernelGGL(k_hist, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->hist);
+    hipLaunchKernelGGL(k_hist, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist);
 
     stamp(p, ST_TREE, st);
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
-    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, g, p->nbuse, nhb, p->cw, p->tdesc, p->meta);
+    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta);
 
     stamp(p, ST_LAYOUT, st);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,

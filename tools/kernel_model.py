@@ -273,3 +273,41 @@ def crc_constants(lanes=64, waves=16):
         wave_shift=[x_pow_bytes(16 * lanes * (waves - 1 - w)) for w in range(waves)],
         row_shift=x_pow_bytes(16 * lanes * waves),
     )
+
+
+# --------------------------------------------------------------------------
+# v2 tokenizer: mask formulation used by k_hist / k_encode (no per-byte state)
+# --------------------------------------------------------------------------
+def _ctz(x):
+    return (x & -x).bit_length() - 1
+
+
+def granule_masks(zm, nv, zb):
+    """(lits, starts): literal positions and positions where a zero-run token starts."""
+    valid = (1 << nv) - 1
+    zm &= valid
+    lits = ~zm & valid
+    starts = zm & ~(zm << 1) & ~1
+    lead = _ctz((~zm & 0xFFFFFFFF) | (1 << nv))
+    if lead > 0:
+        q = (zb >= CAP) + (zb >= 2 * CAP) + (zb >= 3 * CAP)
+        r = zb - q * CAP
+        i_cap = CAP - r if r else 0
+        if i_cap < lead:
+            starts |= 1 << i_cap
+    return lits, starts
+
+
+def granule_tokens_v2(block):
+    nv, zm, zb, za = granule_scan(block)
+    out = []
+    for g in range(len(nv)):
+        lits, starts = granule_masks(zm[g], nv[g], zb[g])
+        for i in range(nv[g]):
+            if (lits >> i) & 1:
+                out.append((int(block[16 * g + i]), 0, 0))
+            elif (starts >> i) & 1:
+                ahead = _ctz(((~(zm[g] >> i)) & 0xFFFFFFFF) | (1 << (nv[g] - i)))
+                rem = ahead + (za[g] if i + ahead == nv[g] else 0)
+                out.append(run_symbol(min(CAP, rem)))
+    return out
