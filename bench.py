@@ -133,45 +133,39 @@ def main():
         got = d_dst[0][0, : int(d_sizes[0][0])].cpu().numpy().tobytes()
         assert got == want, "GPU stream differs from the oracle"
 
-    # gather plan (N>1): sizes by all_gather, payload by packed send/recv to rank 0 on a side stream
+    # gather plan (N>1): each rank packs its streams into a container on the device
+    # (rspt_hip_pack_batch_dev) and the containers go to rank 0 over RCCL: sizes by
+    # all_gather, payload by send/recv (rspt_amd/shard.py).  It runs on a side stream so
+    # that step i's gather overlaps step i+1's compression.
+    from rspt_amd import shard
+
     do_gather = world > 1 and not args.no_gather
     side = torch.cuda.Stream(dev) if do_gather else None
-    packed = [torch.empty(B * dst_stride // 4, dtype=torch.uint8, device=dev) for _ in range(2)] if do_gather else None
-    recv_buf = None
+    bound = pk.pack_bound(B)
+    packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(2)] if do_gather else None
+    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
+    recv_bufs = None
     if do_gather and rank == 0:
-        recv_buf = [torch.empty(B * dst_stride // 4, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
-
-    def gather_step(slot):
-        """pack this rank's streams back to back and ship them to rank 0 (gatherv)."""
-        sizes = d_sizes[slot]
-        total = sizes.sum()
-        offs = torch.cumsum(sizes, 0) - sizes
-        # compaction: one masked copy (device side), no host sync
-        col = torch.arange(dst_stride, device=dev).unsqueeze(0)
-        mask = col < sizes.unsqueeze(1)
-        flat = d_dst[slot][mask]  # streams back to back
-        n = flat.numel()
-        packed[slot][:n] = flat
-        all_tot = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(all_tot, total.view(1))
-        if rank == 0:
-            reqs = []
-            for r in range(1, world):
-                reqs.append(dist.irecv(recv_buf[r - 1][: int(all_tot[r])], src=r))
-            for q in reqs:
-                q.wait()
-        else:
-            dist.send(packed[slot][:n], dst=0)
+        recv_bufs = [None] + [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
+    gathered_bytes = [0]
+    slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
 
     def one_step(i):
         slot = i & 1
+        if slot_free[slot] is not None:
+            stream.wait_event(slot_free[slot])
         pk.compress_batch(d_src, d_dst[slot], d_sizes[slot], dst_stride)
         if do_gather:
+            pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
             ev = torch.cuda.Event()
             ev.record(stream)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                gather_step(slot)
+                got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
+                if got is not None:
+                    gathered_bytes[0] = sum(n for _, n in got)
+                slot_free[slot] = torch.cuda.Event()
+                slot_free[slot].record(side)
 
     def fence():
         torch.cuda.synchronize()
@@ -236,6 +230,7 @@ def main():
                 "blocks_per_gpu": B,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
                 "gather": bool(do_gather),
+                "gathered_bytes_per_step": gathered_bytes[0],
                 "parallelism": "shard%d" % world,
             },
             "roofline": {

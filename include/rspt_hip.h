@@ -118,6 +118,19 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
 int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, size_t nblocks, void* d_dst,
                                   uint64_t* d_consumed, void* stream);
 
+/* ---- container: many streams, back to back (what a multi-GPU gather ships) ---
+ * layout (little-endian):
+ *   u64 magic 'RSPTPACK' | u64 nblocks | u64 payload_bytes | u64 nb (bytes per int32 used by the LAST block)
+ *   nblocks x { u64 offset, u64 length }      offsets relative to the payload, 16-byte aligned
+ *   payload                                    stream b at payload + offset[b], zero padded to 16 bytes
+ * rspt_hip_pack_bound() bytes always suffice for d_packed.  d_total (device u64)
+ * receives the container length.  The reference keeps nb out of the stream
+ * (signal_packer_xdelta_hzr.cpp:39,66); the container carries it so that a
+ * consumer of gathered shards can configure its decoder. */
+size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks);
+int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_stride, const uint64_t* d_sizes, size_t nblocks, void* d_packed,
+                            uint64_t* d_total, void* stream);
+
 /* The handle's own (non-blocking) stream, as a hipStream_t. */
 void* rspt_hip_stream(rspt_hip_packer* p);
 

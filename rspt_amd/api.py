@@ -22,7 +22,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_status_string", "rspt_hip_last_hip_error", "rspt_hip_device_count", "rspt_hip_packer_create",
     "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
-    "rspt_hip_decompress_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
+    "rspt_hip_decompress_batch_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read",
 ]
 
@@ -68,6 +68,9 @@ def lib():
     L.rspt_hip_decompress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rspt_hip_synchronize.restype, L.rspt_hip_synchronize.argtypes = C.c_int, [C.c_void_p]
     L.rspt_hip_stream.restype, L.rspt_hip_stream.argtypes = C.c_void_p, [C.c_void_p]
+    L.rspt_hip_pack_bound.restype, L.rspt_hip_pack_bound.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t]
+    L.rspt_hip_pack_batch_dev.restype = C.c_int
+    L.rspt_hip_pack_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rspt_hip_set_profiling.restype, L.rspt_hip_set_profiling.argtypes = C.c_int, [C.c_void_p, C.c_int]
     L.rspt_hip_stage_count.restype, L.rspt_hip_stage_count.argtypes = C.c_int, [C.c_void_p]
     L.rspt_hip_stage_name.restype, L.rspt_hip_stage_name.argtypes = C.c_char_p, [C.c_void_p, C.c_int]
@@ -175,6 +178,24 @@ class SignalPacker:
         rc = self._L.rspt_hip_decompress_batch_dev(self._h, d_streams.data_ptr(), src_stride, nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
         self._check("rspt_hip_decompress_batch_dev", rc)
         return d_out, d_consumed
+
+    def pack_bound(self, nblocks):
+        return self._L.rspt_hip_pack_bound(self._h, nblocks)
+
+    def pack_batch(self, d_dst, d_sizes, d_packed=None, d_total=None, stream=None):
+        """streams of a batch -> one container (layout: include/rspt_hip.h); asynchronous."""
+        import torch
+
+        nblocks = d_sizes.numel()
+        stride = d_dst.numel() // nblocks
+        if d_packed is None:
+            d_packed = torch.empty(self.pack_bound(nblocks), dtype=torch.uint8, device=d_dst.device)
+        if d_total is None:
+            d_total = torch.zeros(1, dtype=torch.int64, device=d_dst.device)
+        st = stream if stream is not None else torch.cuda.current_stream(d_dst.device).cuda_stream
+        rc = self._L.rspt_hip_pack_batch_dev(self._h, d_dst.data_ptr(), stride, d_sizes.data_ptr(), nblocks, d_packed.data_ptr(), d_total.data_ptr(), st)
+        self._check("rspt_hip_pack_batch_dev", rc)
+        return d_packed, d_total
 
     def synchronize(self):
         self._check("rspt_hip_synchronize", self._L.rspt_hip_synchronize(self._h))

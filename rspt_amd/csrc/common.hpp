@@ -40,13 +40,19 @@ struct Geom {
 
 // CRC-32C constants for the parallel checksum (tools/kernel_model.py:crc_parallel).
 struct CrcConsts {
-    uint32_t table[4][256];   // slice-by-4 LUTs, reflected poly 0x82F63B78; table[0] = hzr_crc32c.c:32
-    uint32_t lane_shift[64];  // x^(8*64*(63-l)): a lane's 64-byte chunk to the end of its wave's 4 KiB slot
-    uint32_t wave_shift[16];  // x^(8*4096*(15-w)): a wave's slot to the end of the 64 KiB window
-    uint32_t big_shift;       // x^(8*65536): the one chunk that can lie in front of the window
-    uint32_t prefix;          // 4 bytes X (LE) with raw_crc(X) = 0xFFFFFFFF
-    uint32_t pad[2];
+    uint32_t table[4][256];  // slice-by-4 LUTs, reflected poly 0x82F63B78; table[0] = hzr_crc32c.c:32
+    // multiplication by a fixed power of x as four byte-indexed lookups (gf_mul is linear in its first operand):
+    //   shift[i][j][b] = gf_mul(b << 8j, K_i),  K_i = x^(8*64*(63-i)) for i < 64 (lane chunk -> end of the wave's 4 KiB slot),
+    //   K_{64+w} = x^(8*4096*(15-w)) (wave slot -> end of the 64 KiB window), K_80 = x^(8*65536) (the one chunk in front of it)
+    uint32_t shift[81][4][256];
+    uint32_t prefix;  // 4 bytes X (LE) with raw_crc(X) = 0xFFFFFFFF
+    uint32_t pad[3];
 };
+
+__device__ __forceinline__ uint32_t gf_shift(const CrcConsts* cc, uint32_t i, uint32_t a) {
+    const uint32_t(*t)[256] = cc->shift[i];
+    return t[0][a & 0xFFu] ^ t[1][(a >> 8) & 0xFFu] ^ t[2][(a >> 16) & 0xFFu] ^ t[3][a >> 24];
+}
 
 // Per-hzr-block record written by k_tree, read by k_layout and k_encode.
 struct BlockMeta {
@@ -193,11 +199,15 @@ __device__ __forceinline__ uint32_t run_extra_value(uint32_t sym, uint32_t z) {
 //   lits    valid non-zero bytes: one literal token each
 //   starts  zero bytes at which a zero-run token starts: a zero whose distance
 //           from its run start is a multiple of 16662 (hzr_encode.c:149,417)
+//   single  tokens without extra bits that are looked up directly: literals (index = byte
+//           value), zero runs of length 1 (symbol 0 = byte value 0) and of length 2 (symbol 256)
+//   two     the subset of `single` that are runs of exactly 2 zeros (lookup index 256)
+//   runs    the remaining run tokens (length >= 3), rare in dense planes
 struct GranuleMasks {
-    uint32_t lits, starts;
+    uint32_t lits, starts, single, two, runs;
 };
 
-__device__ __forceinline__ GranuleMasks granule_masks(uint32_t zm, uint32_t nv, uint32_t zb) {
+__device__ __forceinline__ GranuleMasks granule_masks(uint32_t zm, uint32_t nv, uint32_t zb, uint32_t za) {
     GranuleMasks m;
     const uint32_t valid = (1u << nv) - 1u;
     m.lits = ~zm & valid;
@@ -209,6 +219,12 @@ __device__ __forceinline__ GranuleMasks granule_masks(uint32_t zm, uint32_t nv, 
         const uint32_t icap = r ? kRunCap - r : 0u;
         if (icap < lead) m.starts |= 1u << icap;
     }
+    // zero map extended by the first two bytes behind the granule (bits nv, nv+1 <- za >= 1, za >= 2)
+    const uint32_t ze = zm | ((za >= 1 ? 1u : 0u) << nv) | ((za >= 2 ? 2u : 0u) << nv);
+    const uint32_t len1 = m.starts & ~(ze >> 1);              // next byte is not zero
+    m.two = m.starts & (ze >> 1) & ~(ze >> 2);                // exactly two zeros
+    m.single = m.lits | len1 | m.two;
+    m.runs = m.starts & ~(len1 | m.two);
     return m;
 }
 

@@ -29,44 +29,68 @@ struct LaneBlock {
     uint32_t za[4];  // zeros immediately after granule r (cut at the block end)
 };
 
-// scratch: 2*kEncWaves uint32
-__device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, uint32_t in_size, LaneBlock& L, uint32_t* scratch) {
+// scratch: 2*kEncWaves uint32.  segmask bit w = "the 4 KiB segment of wave w holds a non-zero byte"
+// (front-end non-zero map): a wave whose bit is clear does not read HBM at all.
+__device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, LaneBlock& L, uint32_t* scratch) {
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const bool seg_nz = (segmask >> w) & 1u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t pos = w * 4096 + r * 1024 + l * 16;
         Granule& g = L.g[r];
         g.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (g.nv) v = *reinterpret_cast<const uint4*>(in + pos);  // plane rows are padded: a partial granule may over-read, masked below
+        if (g.nv && seg_nz) v = *reinterpret_cast<const uint4*>(in + pos);  // plane rows are padded: a partial granule may over-read, masked below
         g.w[0] = v.x;
         g.w[1] = v.y;
         g.w[2] = v.z;
         g.w[3] = v.w;
         granule_finish(g);
     }
-    // forward chain (zeros before): rows in order, carry = everything before the row
+    // Zero-run chaining with one ballot + one shuffle per row and direction: the
+    // nearest granule that is not all-zero closes the run (tools/kernel_model.py:granule_scan).
+    const unsigned long long lt = (1ull << l) - 1ull;                       // lanes below
+    const unsigned long long gt = l == 63 ? 0ull : ~((2ull << l) - 1ull);  // lanes above
+    // forward (zeros before): rows in order, carry = everything before the row
     uint32_t carry = kZIdentity;
     uint32_t fwd_incl[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        uint32_t inc = wave_zscan_fwd(granule_trail_elem(L.g[r]));
-        uint32_t exc = (uint32_t)__shfl_up((int)inc, 1, 64);
-        if (l == 0) exc = kZIdentity;
-        fwd_incl[r] = zcomb(carry, exc);  // wave-local exclusive prefix for this lane
-        carry = zcomb(carry, (uint32_t)__shfl((int)inc, 63, 64));
+        const Granule& g = L.g[r];
+        const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
+        const uint32_t trail = granule_trail_elem(g) & ~kZAll;
+        const unsigned long long nonall = ~__ballot(allz);
+        const unsigned long long below = nonall & lt;
+        const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+        const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
+        fwd_incl[r] = below ? (16u * (l - 1u - p) + tp) : zcomb(carry, kZAll | (16u * l));
+        uint32_t rows = kZAll | 1024u;
+        if (nonall) {
+            const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
+            rows = 16u * (63u - ph) + (uint32_t)__shfl((int)trail, (int)ph, 64);
+        }
+        carry = zcomb(carry, rows);
     }
     const uint32_t wave_fwd = carry;
-    // backward chain (zeros after): rows in reverse
+    // backward (zeros after): rows in reverse
     carry = kZIdentity;
     uint32_t bwd_incl[4];
 #pragma unroll
     for (int r = 3; r >= 0; --r) {
-        uint32_t inc = wave_zscan_bwd(granule_lead_elem(L.g[r]));
-        uint32_t exc = (uint32_t)__shfl_down((int)inc, 1, 64);
-        if (l == 63) exc = kZIdentity;
-        bwd_incl[r] = zcomb(carry, exc);
-        carry = zcomb(carry, (uint32_t)__shfl((int)inc, 0, 64));
+        const Granule& g = L.g[r];
+        const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
+        const uint32_t lead = granule_lead_elem(g) & ~kZAll;
+        const unsigned long long nonall = ~__ballot(allz);
+        const unsigned long long above = nonall & gt;
+        const uint32_t q = above ? (uint32_t)__builtin_ctzll(above) : 63u;
+        const uint32_t lq = (uint32_t)__shfl((int)lead, (int)q, 64);
+        bwd_incl[r] = above ? (16u * (q - l - 1u) + lq) : zcomb(carry, kZAll | (16u * (63u - l)));
+        uint32_t rows = kZAll | 1024u;
+        if (nonall) {
+            const uint32_t ql = (uint32_t)__builtin_ctzll(nonall);
+            rows = 16u * ql + (uint32_t)__shfl((int)lead, (int)ql, 64);
+        }
+        carry = zcomb(carry, rows);
     }
     const uint32_t wave_bwd = carry;
     if (l == 0) {
@@ -74,16 +98,39 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
         scratch[kEncWaves + w] = wave_bwd;
     }
     __syncthreads();
-    uint32_t pre = kZIdentity;  // everything before this wave
-    for (uint32_t i = 0; i < w; ++i) pre = zcomb(pre, scratch[i]);
-    uint32_t post = kZIdentity;  // everything after this wave
-    for (int i = kEncWaves - 1; i > (int)w; --i) post = zcomb(post, scratch[kEncWaves + i]);
+    // fold the 16 wave summaries: lane i < 16 takes wave i's, 4-step scans, then pick this wave's neighbours
+    uint32_t sf = l < (uint32_t)kEncWaves ? scratch[l] : kZIdentity;
+    uint32_t sb = l < (uint32_t)kEncWaves ? scratch[kEncWaves + l] : kZIdentity;
+#pragma unroll
+    for (int dd = 1; dd < kEncWaves; dd <<= 1) {
+        const uint32_t of = (uint32_t)__shfl_up((int)sf, dd, 64);
+        const uint32_t ob = (uint32_t)__shfl_down((int)sb, dd, 64);
+        if (l >= (uint32_t)dd) sf = zcomb(of, sf);
+        if (l + (uint32_t)dd < (uint32_t)kEncWaves) sb = zcomb(ob, sb);
+    }
+    uint32_t pre = (uint32_t)__shfl((int)sf, (int)(w ? w - 1 : 0), 64);  // everything before this wave
+    if (w == 0) pre = kZIdentity;
+    uint32_t post = (uint32_t)__shfl((int)sb, (int)(w + 1 < (uint32_t)kEncWaves ? w + 1 : w), 64);  // everything after it
+    if (w + 1 == (uint32_t)kEncWaves) post = kZIdentity;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         L.zb[r] = zcomb(pre, fwd_incl[r]) & ~kZAll;
         L.za[r] = zcomb(post, bwd_incl[r]) & ~kZAll;
     }
     __syncthreads();  // scratch may be reused by the caller
+}
+
+// A wave whose 4 KiB segment is all zero holds a token only where a zero-run token
+// starts: at the block start (no zeros before) or at a multiple of 16662 inside the
+// run (hzr_encode.c:149).  Wave-uniform, so whole waves skip their token loops.
+__device__ __forceinline__ bool wave_may_have_tokens(uint32_t segmask, const LaneBlock& L) {
+    const uint32_t w = threadIdx.x >> 6;
+    if ((segmask >> w) & 1u) return true;
+    const uint32_t zb0 = (uint32_t)__shfl((int)L.zb[0], 0, 64);  // zeros before the wave's first byte
+    const uint32_t q = (zb0 >= kRunCap) + (zb0 >= 2 * kRunCap) + (zb0 >= 3 * kRunCap);
+    const uint32_t r = zb0 - q * kRunCap;
+    const uint32_t icap = r ? kRunCap - r : 0u;  // first byte of the segment at which a token starts
+    return icap < 4096u;
 }
 
 // ===========================================================================
@@ -101,14 +148,14 @@ __device__ __forceinline__ GranuleRegs granule_regs(const LaneBlock& L, int r) {
 }
 __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
                                           uint32_t za, uint32_t* s_hist) {
-    const GranuleMasks m = granule_masks(zm, nv, zb);
+    const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t w[4] = {w0, w1, w2, w3};
 #pragma unroll
     for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        if ((m.lits >> i) & 1u) atomicAdd(&s_hist[x], 1u);
+        const uint32_t x = ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) | (((m.two >> i) & 1u) << 8);
+        if ((m.single >> i) & 1u) atomicAdd(&s_hist[x], 1u);  // literal, lone zero (symbol 0) or two zeros (symbol 256)
     }
-    uint32_t st = m.starts;
+    uint32_t st = m.runs;
     while (st) {
         const uint32_t i = (uint32_t)__builtin_ctz(st);
         st &= st - 1;
@@ -121,22 +168,26 @@ __global__ __launch_bounds__(kEncThreads) void k_hist(const uint8_t* __restrict_
     __shared__ uint32_t s_hist[kSymStride];
     __shared__ uint32_t s_scr[2 * kEncWaves];
     const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
-    if (k >= nbuse[b]) return;
     const uint32_t hb = hb_index(g, b, k, j);
-    if (!nzflag[hb]) return;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
+    const uint32_t nbu = nbuse[b];
+    const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
+    if (k >= nbu) return;
+    if (!segmask) return;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
     const uint32_t tid = threadIdx.x;
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     if (tid < kSymStride) s_hist[tid] = 0;
     LaneBlock L;
-    load_and_chain(in, in_size, L, s_scr);  // contains the barrier that publishes the zeroed histogram
-    GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
+    load_and_chain(in, in_size, segmask, L, s_scr);  // contains the barrier that publishes the zeroed histogram
+    if (wave_may_have_tokens(segmask, L)) {
+        GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-        hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
-        q0 = q1;
-        q1 = q2;
-        q2 = q3;
+        for (int r = 0; r < 4; ++r) {
+            hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
+            q0 = q1;
+            q1 = q2;
+            q2 = q3;
+        }
     }
     __syncthreads();
     if (tid < kSymStride) hist[(size_t)hb * kSymStride + tid] = s_hist[tid];
@@ -382,8 +433,10 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
 // The payload image lives in LDS with one pad word after every 16 words, so
 // that both access patterns are bank-conflict free: consecutive words by
 // consecutive lanes (emit, copy-out) and one 64-byte chunk per lane (CRC).
+// Logical word 0 holds the CRC prefix X, the payload starts at logical byte 4: the image IS the
+// virtual CRC input V = X || payload (tools/kernel_model.py:crc_parallel).
 __device__ __forceinline__ uint32_t skew(uint32_t w) { return w + (w >> 4); }
-constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logical words (payload + read slack)
+constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logical words (X + payload + read slack)
 constexpr uint32_t kStagePhys = kStageWords + (kStageWords >> 4) + 2;   // physical words
 
 struct EncLds {
@@ -397,42 +450,49 @@ struct EncLds {
 
 struct BitSink {
     uint32_t* stage;
-    uint64_t acc;
-    uint32_t n;     // bits held in acc (< 32 between calls)
+    uint32_t lo;    // partial word being assembled (bits below n)
+    uint32_t n;     // bits held in lo (< 32 between calls)
     uint32_t word;  // next logical staging word
     __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
         stage = s;
-        acc = 0;
+        lo = 0;
         n = bitpos & 31u;
         word = bitpos >> 5;
     }
     __device__ __forceinline__ void put(uint32_t v, uint32_t len) {  // len <= 32, v has no bits above len
-        acc |= (uint64_t)v << n;
-        n += len;
-        if (n >= 32) {
-            atomicOr(&stage[skew(word)], (uint32_t)acc);
+        lo |= v << n;
+        const uint32_t tot = n + len;
+        if (tot >= 32) {
+            atomicOr(&stage[skew(word)], lo);
             ++word;
-            acc >>= 32;
-            n -= 32;
+            lo = (v >> 1) >> (31u - n);  // the bits of v that did not fit (v >> (32-n), defined for n = 0)
+            n = tot - 32;
+        } else {
+            n = tot;
         }
     }
     __device__ __forceinline__ void flush() {
-        if (n) atomicOr(&stage[skew(word)], (uint32_t)acc);
+        if (n) atomicOr(&stage[skew(word)], lo);
     }
 };
 
 // pass 1: number of stream bits of the tokens that start in this granule
 __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
                                               uint32_t za, const uint32_t* s_cw) {
-    const GranuleMasks m = granule_masks(zm, nv, zb);
+    const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t w[4] = {w0, w1, w2, w3};
     uint32_t nb = 0;
+    // two batches of 8 independent LDS reads each (a single wait per batch instead of one per byte)
 #pragma unroll
-    for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        if ((m.lits >> i) & 1u) nb += s_cw[x] >> 24;
+    for (uint32_t h = 0; h < 16; h += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) c[i] = s_cw[((w[(h + i) >> 2] >> (((h + i) & 3) * 8)) & 0xFFu) | (((m.two >> (h + i)) & 1u) << 8)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) nb += ((m.single >> (h + i)) & 1u) ? (c[i] >> 24) : 0u;
     }
-    uint32_t st = m.starts;
+    uint32_t st = m.runs;
     while (st) {
         const uint32_t i = (uint32_t)__builtin_ctz(st);
         st &= st - 1;
@@ -442,75 +502,109 @@ __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint3
     return nb;
 }
 
-// pass 2: emit the codes of this granule's tokens at stream bit `bitpos` (hzr_encode.c:410-457)
+// pass 2: emit the codes of this granule's tokens at stream bit `bitpos` (hzr_encode.c:410-457).
+// Tokens without extra bits (literals, 1- and 2-zero runs) are looked up by index and go two
+// at a time (one flush test per pair); the 8 lookups of a half-granule are issued together.
+// A pair that holds a longer run token (rare in dense planes) takes the general path.
 __device__ __forceinline__ void emit_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
-                                          const uint32_t* s_cw, uint32_t* stage, uint32_t bitpos) {
-    const GranuleMasks m = granule_masks(zm, nv, zb);
+                                             const uint32_t* s_cw, uint32_t* stage, uint32_t bitpos) {
+    const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t w[4] = {w0, w1, w2, w3};
     BitSink sink;
     sink.start(stage, bitpos);
 #pragma unroll
-    for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t x = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        if ((m.lits >> i) & 1u) {
-            const uint32_t c = s_cw[x];
-            sink.put(c & 0x00FFFFFFu, c >> 24);
-        } else if ((m.starts >> i) & 1u) {
-            const uint32_t z = run_token_length(zm, nv, za, i);
-            const uint32_t sym = run_symbol(z);
-            const uint32_t c = s_cw[sym];
-            sink.put(c & 0x00FFFFFFu, c >> 24);           // code first ...
-            const uint32_t eb = run_extra_bits(sym);
-            if (eb) sink.put(run_extra_value(sym, z), eb);  // ... then the run's extra bits
+    for (uint32_t h = 0; h < 16; h += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) c[i] = s_cw[((w[(h + i) >> 2] >> (((h + i) & 3) * 8)) & 0xFFu) | (((m.two >> (h + i)) & 1u) << 8)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i += 2) {
+            const uint32_t p0 = h + i, p1 = h + i + 1;
+            const uint32_t c0 = ((m.single >> p0) & 1u) ? c[i] : 0u;
+            const uint32_t c1 = ((m.single >> p1) & 1u) ? c[i + 1] : 0u;
+            if ((m.runs >> p0) & 3u) {
+#pragma unroll
+                for (uint32_t e = p0; e <= p1; ++e) {
+                    const uint32_t ce = e == p0 ? c0 : c1;
+                    if ((m.runs >> e) & 1u) {
+                        const uint32_t z = run_token_length(zm, nv, za, e);
+                        const uint32_t sym = run_symbol(z);
+                        const uint32_t cr = s_cw[sym];
+                        sink.put(cr & 0x00FFFFFFu, cr >> 24);            // code first ...
+                        const uint32_t eb = run_extra_bits(sym);
+                        if (eb) sink.put(run_extra_value(sym, z), eb);  // ... then the run's extra bits
+                    } else {
+                        sink.put(ce & 0x00FFFFFFu, ce >> 24);
+                    }
+                }
+            } else {
+                const uint32_t l0 = c0 >> 24, l1 = c1 >> 24;
+                if (l0 + l1 <= 32) {
+                    sink.put((c0 & 0x00FFFFFFu) | ((c1 & 0x00FFFFFFu) << l0), l0 + l1);
+                } else {
+                    sink.put(c0 & 0x00FFFFFFu, l0);
+                    sink.put(c1 & 0x00FFFFFFu, l1);
+                }
+            }
         }
     }
     sink.flush();
 }
 
-// byte p of the virtual CRC input V = X || payload, in payload coordinates
-// (p in [-4,0) addresses the prefix X, p < -4 the zero front padding)
-__device__ __forceinline__ uint32_t vmsg_byte(const uint32_t* stage, int32_t p, uint32_t prefix) {
-    if (p >= 0) return (stage[skew((uint32_t)p >> 2)] >> (((uint32_t)p & 3u) * 8)) & 0xFFu;
-    if (p >= -4) return (prefix >> ((p + 4) * 8)) & 0xFFu;
-    return 0;
-}
+// byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
+__device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[skew(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }
 
-// raw CRC state (from 0) after the 64 bytes [lo, lo+64) of V
-__device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo, uint32_t L, uint32_t prefix) {
+// raw CRC state (from 0) after the 64 bytes [lo, lo+64) of V; bytes in front of V (lo < 0) are zero
+__device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo) {
+    const int32_t a = lo >> 2;  // arithmetic: floor
+    const uint32_t sh = (uint32_t)lo & 3u;
     uint32_t c = 0;
-    if (lo >= 0) {
-        const uint32_t a = (uint32_t)lo >> 2, sh = (uint32_t)lo & 3u;
-        uint32_t prev = d.stage[skew(a)];
+    uint32_t prev = a >= 0 ? d.stage[skew((uint32_t)a)] : 0u;
 #pragma unroll
-        for (uint32_t q = 0; q < 16; ++q) {
-            const uint32_t next = d.stage[skew(a + q + 1)];
-            c ^= __builtin_amdgcn_alignbyte(next, prev, sh);
-            prev = next;
-            c = d.crc[3][c & 0xFFu] ^ d.crc[2][(c >> 8) & 0xFFu] ^ d.crc[1][(c >> 16) & 0xFFu] ^ d.crc[0][c >> 24];
-        }
-    } else {
-        for (int32_t p = lo; p < lo + 64; ++p) {
-            c ^= vmsg_byte(d.stage, p, prefix);
-            c = (c >> 8) ^ d.crc[0][c & 0xFFu];
-        }
+    for (int32_t q = 0; q < 16; ++q) {
+        const int32_t ix = a + q + 1;
+        const uint32_t next = ix >= 0 ? d.stage[skew((uint32_t)ix)] : 0u;
+        c ^= __builtin_amdgcn_alignbyte(next, prev, sh);
+        prev = next;
+        c = d.crc[3][c & 0xFFu] ^ d.crc[2][(c >> 8) & 0xFFu] ^ d.crc[1][(c >> 16) & 0xFFu] ^ d.crc[0][c >> 24];
     }
     return c;
 }
 
+// `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
+// emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
 __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                       const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
-                                                       const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
-                                                       const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride) {
+                                                       const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
+                                                       const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
+                                                       const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
+                                                       uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate,
+                                                       unsigned long long* __restrict__ stamps) {
     __shared__ EncLds d;
+    // diagnostic (ablate bit 7): lane 0 of every wave of the first 512 hzr blocks stores s_memtime at section seams
+#define RSPT_STAMP(i)                                                                                      \
+    do {                                                                                                   \
+        if ((ablate & 128u) && (threadIdx.x & 63u) == 0 && hb_index(g, blockIdx.z, blockIdx.y, blockIdx.x) < 512u) \
+            stamps[(hb_index(g, blockIdx.z, blockIdx.y, blockIdx.x) * 16u + (threadIdx.x >> 6)) * 8u + (i)] = __builtin_amdgcn_s_memtime();      \
+    } while (0)
     const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
-    if (k >= nbuse[b]) return;
     const uint32_t hb = hb_index(g, b, k, j);
+    // three independent loads in one round trip (their addresses depend on the block index only)
+    const BlockMeta m = meta[hb];
     const uint64_t off = out_off[hb];
+    const uint32_t segmask = nzflag[hb];
+    if (m.mode == kModeSkip || (ablate & 16u)) return;  // plane not used by this block (k >= nb)
     if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const BlockMeta m = meta[hb];
     uint8_t* o = dst + (size_t)b * dst_stride + off;
 
+    if (ablate & 64u) {  // occupancy census: every non-fill workgroup idles ~100 us (s_memrealtime ticks at 100 MHz)
+        if (m.mode != kModeFill) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
+        }
+        return;
+    }
     if (m.mode == kModeFill) {  // EncodeFill (hzr_encode.c:341-367): [00 00][crc32c(value)][02][value]
         if (tid == 0) {
             uint32_t c = 0xFFFFFFFFu ^ m.fill;
@@ -530,6 +624,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     const uint32_t L = m.payload_len;
+    RSPT_STAMP(0);
     {
         const uint32_t* t = &cc->table[0][0];
         uint32_t* dt = &d.crc[0][0];
@@ -538,18 +633,21 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
 
     if (m.mode == kModeHuff) {
         // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
-        const uint32_t zwords = skew((L >> 2) + 24);
+        const uint32_t zwords = skew(((L + 4) >> 2) + 24);
         for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
         if (tid < kSymStride) d.cw[tid] = cw[(size_t)hb * kSymStride + tid];
         LaneBlock B;
-        load_and_chain(in, in_size, B, d.scr);  // barriers inside publish cw and the zeroed image
-        const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219)
-        if (tid < twords) atomicOr(&d.stage[skew(tid)], tdesc[(size_t)hb * kTdescWords + tid]);
+        load_and_chain(in, in_size, segmask, B, d.scr);  // barriers inside publish cw and the zeroed image
+        if (ablate & 32u) return;
+        RSPT_STAMP(1);
+        const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
+        if (tid < twords) atomicOr(&d.stage[skew(1 + tid)], tdesc[(size_t)hb * kTdescWords + tid]);
+        const bool active = wave_may_have_tokens(segmask, B);  // wave-uniform
         GranuleRegs q0 = granule_regs(B, 0), q1 = granule_regs(B, 1), q2 = granule_regs(B, 2), q3 = granule_regs(B, 3);
         uint32_t nbits[4] = {0, 0, 0, 0};
 #pragma unroll 1
-        for (int r = 0; r < 4; ++r) {  // rolled: granules and results rotate through fixed registers
-            const uint32_t nbv = bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw);
+        for (int r = 0; r < 4 && active; ++r) {  // rolled: granules and results rotate through fixed registers
+            const uint32_t nbv = (ablate & 4u) ? 100u : bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw);
             const GranuleRegs t = q0;
             q0 = q1;
             q1 = q2;
@@ -560,6 +658,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
             nbits[2] = nbits[3];
             nbits[3] = nbv;
         }
+        RSPT_STAMP(2);
         // exclusive bit offsets in byte order: wave w rows 0..3, lanes 0..63
         uint32_t excl[4];
         uint32_t run = 0;
@@ -571,13 +670,14 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         }
         if (l == 0) d.wsum[w] = run;
         __syncthreads();
-        uint32_t wbase = m.tree_bits;
+        uint32_t wbase = 32u + m.tree_bits;  // the payload starts at logical byte 4
         for (uint32_t i = 0; i < w; ++i) wbase += d.wsum[i];
+        RSPT_STAMP(3);
         uint32_t pos0 = wbase + excl[0], pos1 = wbase + excl[1], pos2 = wbase + excl[2], pos3 = wbase + excl[3];
         uint32_t nz0 = nbits[0], nz1 = nbits[1], nz2 = nbits[2], nz3 = nbits[3];
 #pragma unroll 1
-        for (int r = 0; r < 4; ++r) {  // after four rotations q0..q3 are back in order
-            if (nz0) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw, d.stage, pos0);
+        for (int r = 0; r < 4 && active; ++r) {  // after four rotations q0..q3 are back in order
+            if (nz0 && !(ablate & 1u)) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw, d.stage, pos0);
             q0 = q1;
             q1 = q2;
             q2 = q3;
@@ -590,32 +690,37 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         }
     } else {
         // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
-        for (uint32_t gi = tid; gi < kStageWords / 4; gi += kEncThreads) {
+        for (uint32_t gi = tid; gi < kStageWords / 4 - 1; gi += kEncThreads) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (gi * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)gi * 16);
-            const uint32_t p = skew(gi * 4);  // the 4 words of a granule stay adjacent under the skew
-            d.stage[p] = v.x;
-            d.stage[p + 1] = v.y;
-            d.stage[p + 2] = v.z;
-            d.stage[p + 3] = v.w;
+            d.stage[skew(1 + gi * 4)] = v.x;
+            d.stage[skew(2 + gi * 4)] = v.y;
+            d.stage[skew(3 + gi * 4)] = v.z;
+            d.stage[skew(4 + gi * 4)] = v.w;
         }
     }
+    if (tid == 0) d.stage[0] = cc->prefix;  // X (after this thread's own zeroing of word 0)
+    RSPT_STAMP(4);
     __syncthreads();
+    RSPT_STAMP(5);
 
-    // ---- CRC-32C of payload bytes [0, L): virtual message V = X || payload, cut into
-    //      64-byte chunks counted from its END; lane tid owns chunk (1023 - tid) --------
+    // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0), cut into 64-byte
+    //      chunks counted from its END; lane tid owns chunk (1023 - tid); crc = ~raw(V) --------
     {
-        const uint32_t prefix = cc->prefix;
-        const int32_t hi = (int32_t)L - 64 * (int32_t)(kEncThreads - 1 - tid);
+        const int32_t Lv = (int32_t)L + 4;
+        const int32_t hi = Lv - 64 * (int32_t)(kEncThreads - 1 - tid);
         uint32_t c = 0;
-        if (hi > -4) c = crc_chunk64(d, hi - 64, L, prefix);
-        uint32_t red = 0;
-        if (__ballot(c != 0)) red = wave_xor_u32(gf_mul(c, cc->lane_shift[l]));
-        if (l == 0) {
-            uint32_t v = gf_mul(red, cc->wave_shift[w]);
-            // the only chunk that can precede the 64 KiB window (L + 4 > 65536): X and up to 3 payload bytes
-            if (w == 0 && L + 4 > kHzrBlock) v ^= gf_mul(crc_chunk64(d, (int32_t)L - 64 * (int32_t)kEncThreads - 64, L, prefix), cc->big_shift);
-            d.wsum[w] = v;
+        if (hi > 0 && !(ablate & 2u)) c = crc_chunk64(d, hi - 64);
+        if (__ballot(c != 0)) {  // waves without data skip the shift
+            const uint32_t red = wave_xor_u32(gf_shift(cc, l, c));
+            if (l == 0) {
+                uint32_t v = gf_shift(cc, 64 + w, red);
+                // the only chunk that can precede the 64 KiB window (Lv > 65536)
+                if (w == 0 && Lv > (int32_t)kHzrBlock) v ^= gf_shift(cc, 80, crc_chunk64(d, Lv - 64 * (int32_t)kEncThreads - 64));
+                d.wsum[w] = v;
+            }
+        } else if (l == 0) {
+            d.wsum[w] = 0;
         }
         __syncthreads();
         if (tid == 0) {
@@ -626,6 +731,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         __syncthreads();
     }
 
+    RSPT_STAMP(6);
     // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
     if (tid == 0) {
         const uint32_t crc = d.crc_out;
@@ -641,12 +747,89 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
     const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
     const uint32_t nd = (L - head) >> 2;
     const uint32_t tail = L - head - 4 * nd;
-    if (tid < head) po[tid] = (uint8_t)vmsg_byte(d.stage, (int32_t)tid, 0);
-    if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)vmsg_byte(d.stage, (int32_t)(head + 4 * nd + tid), 0);
+    if (tid < head) po[tid] = (uint8_t)stage_byte(d.stage, 4 + tid);
+    if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)stage_byte(d.stage, 4 + head + 4 * nd + tid);
     uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
+    if (ablate & 8u) return;
     for (uint32_t i = tid; i < nd; i += kEncThreads) {
-        // payload bytes [head+4i, head+4i+4): off the LDS word grid by (head & 3)
-        pw[i] = __builtin_amdgcn_alignbyte(d.stage[skew(i + 1)], d.stage[skew(i)], head);
+        // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
+        pw[i] = __builtin_amdgcn_alignbyte(d.stage[skew(i + 2)], d.stage[skew(i + 1)], head);
+    }
+    RSPT_STAMP(7);
+#undef RSPT_STAMP
+}
+
+// ===========================================================================
+// container packing (rspt_hip_pack_batch_dev)
+// ===========================================================================
+constexpr uint64_t kPackMagic = 0x4B43415054505352ull;  // "RSPTPACK"
+constexpr uint32_t kPackHead = 32;                      // magic, nblocks, payload bytes, nb
+
+__global__ __launch_bounds__(1024) void k_pack_index(const uint64_t* __restrict__ sizes, uint32_t nblocks, const uint32_t* __restrict__ nb_state,
+                                                    uint8_t* __restrict__ packed, uint64_t* __restrict__ total) {
+    __shared__ uint64_t s_w[16];
+    __shared__ uint64_t s_carry;
+    uint64_t* head = reinterpret_cast<uint64_t*>(packed);
+    uint64_t* index = head + 4;
+    const uint32_t tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nblocks; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint64_t len = i < nblocks ? (sizes[i] & ~(1ull << 63)) : 0ull;
+        const uint64_t v = (len + 15ull) & ~15ull;
+        uint64_t inc = v;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint64_t o = (uint64_t)__shfl_up((long long)inc, dd, 64);
+            if (l >= (uint32_t)dd) inc += o;
+        }
+        if (l == 63) s_w[w] = inc;
+        __syncthreads();
+        uint64_t pre = s_carry, tot = s_carry;
+        for (uint32_t q = 0; q < 16; ++q) {
+            if (q < w) pre += s_w[q];
+            tot += s_w[q];
+        }
+        if (i < nblocks) {
+            index[2 * i] = pre + inc - v;
+            index[2 * i + 1] = len;
+        }
+        __syncthreads();
+        if (tid == 0) s_carry = tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        head[0] = kPackMagic;
+        head[1] = nblocks;
+        head[2] = s_carry;
+        head[3] = *nb_state;
+        *total = kPackHead + 16ull * nblocks + s_carry;
+    }
+}
+
+// grid (chunks, nblocks): 16-byte units of stream b, strided over the chunk workgroups
+__global__ __launch_bounds__(256) void k_pack_copy(const uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t nblocks,
+                                                  uint8_t* __restrict__ packed) {
+    const uint32_t b = blockIdx.y;
+    const uint64_t* index = reinterpret_cast<const uint64_t*>(packed) + 4;
+    const uint64_t off = index[2 * b], len = index[2 * b + 1];
+    const uint8_t* s = dst + (size_t)b * dst_stride;
+    uint8_t* o = packed + kPackHead + 16ull * nblocks + off;
+    const uint64_t units = (len + 15) >> 4;
+    for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (uint64_t)gridDim.x * 256) {
+        uint4 v = *reinterpret_cast<const uint4*>(s + u * 16);
+        if (u * 16 + 16 > len) {  // zero the padding so that containers are reproducible
+            const uint32_t keep = (uint32_t)(len - u * 16);
+            uint32_t x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t lo = q * 4;
+                x[q] = keep >= lo + 4 ? x[q] : keep <= lo ? 0u : (x[q] & ((1u << ((keep - lo) * 8)) - 1u));
+            }
+            v = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        *reinterpret_cast<uint4*>(o + u * 16) = v;
     }
 }
 

@@ -10,11 +10,11 @@
 //   nb escalation test      signal_packer_xdelta_hzr.cpp:59-69, as the exact
 //                           "fits in nb bytes" reduction
 //
-// Layout.  The input is sample-major ([ns][nch][bps]), so a tile of T samples x
-// all channels is ONE contiguous byte range: it is loaded with 16-byte coalesced
-// reads into LDS, read back with lane<->channel (consecutive LDS words), and
-// the plane bytes go through a second LDS region so that every plane row leaves
-// as 16-byte coalesced stores (T contiguous bytes per channel per plane).
+// Layout.  The input is sample-major ([ns][nch][bps]): with lane <-> channel every
+// wave load is a contiguous row segment, so the transform reads straight from HBM
+// and keeps 16 samples of one channel in registers; only the plane bytes pass
+// through LDS, so that every plane row leaves as 16-byte coalesced stores
+// (T contiguous bytes per channel per plane).
 #include "common.hpp"
 
 namespace rspt {
@@ -48,43 +48,40 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
 // One workgroup = one tile of T samples x all channels of one block.
 //   XDELTA  true : v = (p[i]-p[i-1]-128) ^ (p[i-1]-p[i-2]-128), flat order; accumulates needmask
 //           false: v = p (hzr packer)
-//   NPLANES planes written (4: nb may escalate up to 4 and the planes must be there)
-// LDS: [ in tile: T*nch*BPS + 16 ][ out: NPLANES*nch rows of (T+16) bytes ]
+// Work item = (channel c, 16 consecutive samples); consecutive lanes take consecutive
+// channels, so each of an item's 18 loads is, across the wave, one contiguous row
+// segment of the sample-major input (256 B for 64 int32 channels) -- no input staging.
+// The four plane words of an item go to LDS rows [plane][channel][T+16] and leave as
+// 16-byte coalesced stores, T contiguous bytes per (plane, channel).
+// Planes [kfirst, kfirst+kcount) are written.  The main pass (nbuse == nullptr) writes the
+// planes the host knows are needed (kfirst = 0, kcount = nb as last seen) and computes the
+// escalation magnitude and the non-zero map for all four planes; if nb escalates in this very
+// call (signal_packer_xdelta_hzr.cpp:63-69), a second launch with nbuse != nullptr adds the
+// missing planes for exactly the blocks that need them and exits at once for all others.
 template <int BPS, bool XDELTA>
-__global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t in_lds_bytes,
+__global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                      uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
-                                                     uint32_t* __restrict__ nzflag) {
+                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t b = blockIdx.y;
+    const bool fixup = nbuse != nullptr;
+    if (fixup && nbuse[b] <= kfirst) return;
     const uint32_t s0 = blockIdx.x * T;
     const uint32_t Tn = min(T, g.ns - s0);
     const uint8_t* blk = src + (size_t)b * g.block_bytes;
-    const uint32_t rowb = g.nch * BPS;
+    const bool aligned4 = (BPS == 4) && ((reinterpret_cast<uintptr_t>(blk) & 3u) == 0);
 
-    // ---- phase 1: contiguous tile -> LDS, 16 B per lane --------------------
-    const size_t gs = (size_t)s0 * rowb;
-    const size_t ge = gs + (size_t)Tn * rowb;
-    const uintptr_t abs_s = reinterpret_cast<uintptr_t>(blk) + gs;
-    const uint32_t lo = (uint32_t)(abs_s & 15);  // tile starts `lo` bytes into its first 16-byte chunk
-    const uint8_t* abase = reinterpret_cast<const uint8_t*>(abs_s - lo);
-    const uint32_t span = lo + (uint32_t)(ge - gs);
-    for (uint32_t o = tid * 16; o < span; o += 256 * 16) {
-        uint4 v = *reinterpret_cast<const uint4*>(abase + o);
-        *reinterpret_cast<uint4*>(lds + o) = v;
-    }
-    uint8_t* out = lds + in_lds_bytes;
+    uint8_t* out = lds;
     const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
-    // "this hzr block holds a non-zero byte" flags, first setter in the workgroup forwards to HBM.
-    // A tile row (<= 8192 samples) touches at most two hzr blocks: [rel][plane][channel].
-    uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)4 * g.nch * RS);
+    // Non-zero map: bit s of nzflag[hzr block] = "4 KiB segment s of the block holds a non-zero byte".
+    // The first setter of a bit in the workgroup forwards it to HBM.  A tile row (<= 2048
+    // samples) touches at most two hzr blocks: dedupe masks are kept as [rel][plane][channel].
+    uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)kcount * g.nch * RS);
     for (uint32_t i = tid; i < 8 * g.nch; i += 256) s_nz[i] = 0;
     __syncthreads();
 
-    const bool aligned4 = (BPS == 4) && ((lo & 3) == 0);
-    const uint8_t* tile = lds + lo;
-
-    // ---- phase 2: per (channel, 16-sample group): transform + plane split ---
+    // ---- per (channel, 16-sample group): load, transform, plane split ---------
     const uint32_t ngrp = (Tn + 15) >> 4;
     const uint32_t nitems = g.nch * ngrp;
     uint32_t mag = 0;
@@ -93,14 +90,19 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
         const uint32_t c = q - grp * g.nch;
         const uint32_t t0 = grp << 4;
         const uint32_t cnt = min(16u, Tn - t0);
-        uint32_t p1 = 0, p2 = 0;  // p[i-1], p[i-2]
-        uint32_t oprev = 0;       // o[i-1]
+        const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
+        const size_t rstride = (size_t)g.nch * BPS;
+        uint32_t pv[16];
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+        uint32_t p1 = 0, oprev = 0;  // p[i-1], o[i-1]
         if (XDELTA) {
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
-            if (t0 >= 2) {
-                p1 = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 - 1) * g.nch + c) * BPS, aligned4);
-                p2 = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 - 2) * g.nch + c) * BPS, aligned4);
-            } else {
+            uint32_t p2;
+            if (s0 + t0 >= 2) {  // same channel, two samples back
+                p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
+                p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
+            } else {  // channel start: the flat array continues from the end of channel c-1
                 p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
                 p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
             }
@@ -110,15 +112,15 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
 #pragma unroll
         for (uint32_t e = 0; e < 16; ++e) {
             if (e < cnt) {
-                uint32_t p = (uint32_t)sample_from_bytes<BPS>(tile + ((size_t)(t0 + e) * g.nch + c) * BPS, aligned4);
+                const uint32_t p = pv[e];
                 uint32_t v;
                 if (XDELTA) {
-                    uint32_t o = p - p1 - 128u;
+                    const uint32_t o = p - p1 - 128u;
                     v = o ^ oprev;
                     oprev = o;
                     p1 = p;
                     // sign-extend from the sample width, fold to a magnitude (escalation test)
-                    int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
+                    const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
                     mag |= (uint32_t)(x ^ (x >> 31));
                 } else {
                     v = p;
@@ -135,32 +137,34 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
             uint4 w = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
-            *reinterpret_cast<uint4*>(out + (size_t)(k * g.nch + c) * RS + t0) = w;
-            if (w.x | w.y | w.z | w.w) {
+            if (k >= kfirst && k < kfirst + kcount) *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = w;
+            if (!fixup && (w.x | w.y | w.z | w.w)) {  // (an item straddling a segment edge marks both sides: conservative)
                 const uint32_t ja = f0 >> 16, jz = f1 >> 16;
-                if (atomicOr(&s_nz[((ja - jb) * 4 + k) * g.nch + c], 1u) == 0) atomicOr(&nzflag[hb_index(g, b, k, ja)], 1u);
-                if (jz != ja && atomicOr(&s_nz[((jz - jb) * 4 + k) * g.nch + c], 1u) == 0) atomicOr(&nzflag[hb_index(g, b, k, jz)], 1u);
+                const uint32_t ba = 1u << ((f0 >> 12) & 15u), bz = 1u << ((f1 >> 12) & 15u);
+                if (!(atomicOr(&s_nz[((ja - jb) * 4 + k) * g.nch + c], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
+                if ((jz != ja || bz != ba) && !(atomicOr(&s_nz[((jz - jb) * 4 + k) * g.nch + c], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
             }
         }
     }
-    if (XDELTA) {
+    if (XDELTA && !fixup) {
         mag = wave_or_u32(mag);
         if (lane_id() == 0 && mag) atomicOr(&needmask[b], mag);
     }
     __syncthreads();
 
-    // ---- phase 3: plane rows -> HBM ------------------------------------------
+    // ---- plane rows -> HBM ------------------------------------------------------
     const uint32_t upr = ngrp;  // 16-byte units per row
-    const uint32_t nunits = 4 * g.nch * upr;
+    const uint32_t nunits = kcount * g.nch * upr;
     const bool fast = ((g.ns & 15) == 0) && ((s0 & 15) == 0);
     for (uint32_t u = tid; u < nunits; u += 256) {
-        const uint32_t row = u / upr;  // k*nch + c
-        const uint32_t col = u - row * upr;
-        const uint32_t k = row / g.nch;
-        const uint32_t c = row - k * g.nch;
-        const uint32_t nbytes = min(16u, Tn - col * 16);
-        const uint8_t* sp = out + (size_t)row * RS + col * 16;
-        uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + col * 16;
+        const uint32_t row = u / upr;  // (k-kfirst)*nch + c
+        const uint32_t colu = u - row * upr;
+        const uint32_t kr = row / g.nch;
+        const uint32_t c = row - kr * g.nch;
+        const uint32_t k = kfirst + kr;
+        const uint32_t nbytes = min(16u, Tn - colu * 16);
+        const uint8_t* sp = out + (size_t)row * RS + colu * 16;
+        uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + colu * 16;
         if (fast && nbytes == 16) {
             *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
         } else {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
     for (uint32_t k = 0; k < nplanes; ++k) {
         const bool nz = (pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0;
         const unsigned long long any = __ballot(nz);
-        if (any && lane_id() == (uint32_t)__builtin_ctzll(__ballot(1))) atomicOr(&nzflag[hb_index(g, b, k, i0 >> 16)], 1u);
+        if (any && lane_id() == (uint32_t)__builtin_ctzll(__ballot(1))) atomicOr(&nzflag[hb_index(g, b, k, i0 >> 16)], 1u << ((i0 >> 12) & 15u));
         uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + i0;
         if (cnt == 16) {
             *reinterpret_cast<uint4*>(dp) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
@@ -288,8 +292,8 @@ __global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ n
 
 // explicit instantiations used by rspt_hip.cpp
 #define INST_TILE(BPS)                                                                                                   \
-    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*);    \
-    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*);   \
+    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*);    \
+    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*);   \
     template __global__ void k_tile_planar<BPS>(const uint8_t*, Geom, uint32_t, int32_t*);
 INST_TILE(1)
 INST_TILE(2)

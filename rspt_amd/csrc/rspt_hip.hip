@@ -53,9 +53,11 @@ void make_crc_consts(CrcConsts& cc) {
     }
     for (int t = 1; t < 4; ++t)  // slice-by-4: table[t][b] = state after byte b followed by t zero bytes
         for (uint32_t b = 0; b < 256; ++b) cc.table[t][b] = (cc.table[t - 1][b] >> 8) ^ cc.table[0][cc.table[t - 1][b] & 0xFFu];
-    for (int l = 0; l < 64; ++l) cc.lane_shift[l] = x_pow_bytes(64ull * (63 - l));
-    for (int w = 0; w < 16; ++w) cc.wave_shift[w] = x_pow_bytes(4096ull * (15 - w));
-    cc.big_shift = x_pow_bytes(65536);
+    for (int i = 0; i < 81; ++i) {
+        const uint32_t K = i < 64 ? x_pow_bytes(64ull * (63 - i)) : i < 80 ? x_pow_bytes(4096ull * (15 - (i - 64))) : x_pow_bytes(65536);
+        for (int jx = 0; jx < 4; ++jx)
+            for (uint32_t b = 0; b < 256; ++b) cc.shift[i][jx][b] = gf_mul(b << (8 * jx), K);
+    }
     // X with raw_crc(X) = 0xFFFFFFFF: the 4-byte raw CRC map is linear and invertible
     uint32_t img[32];
     for (int b = 0; b < 32; ++b) img[b] = raw_crc4(1u << b);
@@ -83,7 +85,7 @@ void make_crc_consts(CrcConsts& cc) {
     uint32_t x = 0;
     for (int bit = 0; bit < 32; ++bit) x ^= rows_t[piv[bit]];  // target has every bit set
     cc.prefix = x;
-    cc.pad[0] = cc.pad[1] = 0;
+    cc.pad[0] = cc.pad[1] = cc.pad[2] = 0;
 }
 
 enum Stage { ST_PRE = 0, ST_NB, ST_HIST, ST_TREE, ST_LAYOUT, ST_ENCODE, ST_COUNT };
@@ -97,6 +99,7 @@ struct rspt_hip_packer {
     hipStream_t stream = nullptr;
     int last_hip_error = 0;
     unsigned nb_ctor = 0;
+    unsigned nb_host = 0;  // last value of the device nb_state the host has seen (a lower bound: nb only grows)
 
     // workspace
     size_t cap_blocks = 0;
@@ -132,7 +135,11 @@ struct rspt_hip_packer {
     size_t h_dst_cap = 0;
 
     // tile geometry for the front end
-    uint32_t T = 0, in_lds = 0, lds_total = 0;
+    uint32_t T = 0, in_lds = 0;  // k_tile_planar: tile staged in LDS
+    uint32_t Tp[5] = {0, 0, 0, 0, 0};  // k_tile_planes: tile length when kcount planes are staged: rows [kcount*nch][Tp+16] + nz flags
+
+    unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
+    uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
 
     // profiling
     bool profiling = false;
@@ -153,20 +160,40 @@ static void stamp(rspt_hip_packer* p, int i, hipStream_t st) {
     if (p->profiling) hipEventRecord(p->ev[i], st);
 }
 
-template <int BPS>
-static void launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, hipStream_t st) {
+template <int BPS, bool XD>
+static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, uint32_t kfirst, uint32_t kcount, const uint32_t* nbuse,
+                          hipStream_t st) {
     const Geom& g = p->g;
-    dim3 grid((g.ns + p->T - 1) / p->T, (unsigned)nblocks);
+    const uint32_t T = p->Tp[kcount];
+    const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch;
+    dim3 grid((g.ns + T - 1) / T, (unsigned)nblocks);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse);
+}
+
+// main front-end pass; returns the number of planes it wrote (xdelta: nb as last seen by the host)
+template <int BPS>
+static uint32_t launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, hipStream_t st) {
+    const Geom& g = p->g;
     if (g.kind == RSPT_HIP_KIND_XDELTA_HZR) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_total);
-        hipLaunchKernelGGL((k_tile_planes<BPS, true>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask, p->nzflag);
-    } else if (g.kind == RSPT_HIP_KIND_HZR) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_total);
-        hipLaunchKernelGGL((k_tile_planes<BPS, false>), grid, dim3(256), p->lds_total, st, d_src, g, p->T, p->in_lds, p->planes, p->needmask, p->nzflag);
-    } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planar<BPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->in_lds);
-        hipLaunchKernelGGL((k_tile_planar<BPS>), grid, dim3(256), p->in_lds, st, d_src, g, p->T, p->planar);
+        const uint32_t np = p->nb_host;
+        launch_planes<BPS, true>(p, d_src, nblocks, 0, np, nullptr, st);
+        return np;
     }
+    if (g.kind == RSPT_HIP_KIND_HZR) {
+        launch_planes<BPS, false>(p, d_src, nblocks, 0, 4, nullptr, st);
+        return 4;
+    }
+    dim3 grid((g.ns + p->T - 1) / p->T, (unsigned)nblocks);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planar<BPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->in_lds);
+    hipLaunchKernelGGL((k_tile_planar<BPS>), grid, dim3(256), p->in_lds, st, d_src, g, p->T, p->planar);
+    return 4;
+}
+
+// escalation fix-up: planes [np, 4) for the blocks whose nb grew past np in this call
+template <int BPS>
+static void launch_fixup(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, uint32_t np, hipStream_t st) {
+    launch_planes<BPS, true>(p, d_src, nblocks, np, 4 - np, p->nbuse, st);
 }
 
 extern "C" {
@@ -250,31 +277,45 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     g.method = kind == RSPT_HIP_KIND_DCT ? 1u : kind == RSPT_HIP_KIND_HADAMARD ? 2u : 0u;
     g.plane_stride = ((uint64_t)g.N + 255ull) & ~255ull;
     g.block_bytes = (uint64_t)bps * nch * ns;
-    p->nb_ctor = kind == RSPT_HIP_KIND_HZR ? 4u : kind == RSPT_HIP_KIND_DCT ? 2u : kind == RSPT_HIP_KIND_HADAMARD ? 3u : (unsigned)nb;
+    p->nb_host = p->nb_ctor = kind == RSPT_HIP_KIND_HZR ? 4u : kind == RSPT_HIP_KIND_DCT ? 2u : kind == RSPT_HIP_KIND_HADAMARD ? 3u : (unsigned)nb;
 
-    // tile geometry: in tile (T*nch*bps + 16) + out rows (4*nch*(T+16)) within the LDS budget
+    // tile geometry
     {
         const uint64_t rowb = (uint64_t)g.nch * g.bps;
-        auto fit = [&](uint64_t budget) -> uint32_t {
-            const uint64_t fixed = 32 + 64ull * g.nch + 32ull * g.nch;  // slack + row pads + nz flags
-            if (budget <= fixed) return 0;
-            uint64_t t = (budget - fixed) / (rowb + 4ull * g.nch);
-            t &= ~15ull;
-            return (uint32_t)(t > 8192 ? 8192 : t);
-        };
-        uint32_t T = fit(72 * 1024);
-        if (T < 16) T = fit(150 * 1024);
-        if (T < 16) {
+        const uint32_t ns16 = (g.ns + 15u) & ~15u;
+        // k_tile_planar stages the contiguous input tile (T*nch*bps + 32 bytes) in LDS
+        uint64_t t = (64 * 1024 - 32) / rowb;
+        t &= ~15ull;
+        if (t < 16) {
             delete p;
             return RSPT_HIP_ERR_UNSUPPORTED;
         }
-        uint32_t ns16 = (g.ns + 15u) & ~15u;
-        if (T > ns16) T = ns16;
-        p->T = T;
-        p->in_lds = (uint32_t)(((uint64_t)T * rowb + 16 + 15) & ~15ull);
-        p->lds_total = p->in_lds + 4u * g.nch * (T + 16u) + 32u * g.nch;
+        p->T = (uint32_t)(t > 4096 ? 4096 : t);
+        if (p->T > ns16) p->T = ns16;
+        p->in_lds = (uint32_t)(((uint64_t)p->T * rowb + 16 + 15) & ~15ull);
+        // k_tile_planes keeps only the plane rows in LDS: kcount*nch*(Tp+16) + 32*nch bytes, <= 72 KiB
+        // (two workgroups per CU).  Long row segments matter more than occupancy here: 256-byte plane
+        // rows beat 64-byte ones by 2.5x (profiles/r01_tile_sweep.txt).
+        for (uint32_t kc = 1; kc <= 4; ++kc) {
+            auto fit = [&](uint64_t budget) -> uint32_t {
+                const uint64_t fixed = (16ull * kc + 32ull) * g.nch;
+                if (budget <= fixed) return 0;
+                uint64_t tt = (budget - fixed) / ((uint64_t)kc * g.nch);
+                tt &= ~15ull;
+                return (uint32_t)(tt > 2048 ? 2048 : tt);
+            };
+            uint32_t Tp = fit(72 * 1024);
+            if (Tp < 16) Tp = fit(150 * 1024);
+            if (const char* e = getenv("RSPT_TILE")) Tp = (uint32_t)atoi(e) & ~15u;  // tuning knob
+            if (Tp < 16) {
+                delete p;
+                return RSPT_HIP_ERR_UNSUPPORTED;
+            }
+            if (Tp > ns16) Tp = ns16;
+            p->Tp[kc] = Tp;
+        }
     }
-
+    if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
     {
         // k_planar_native tile: nch rows of (T+1) int32 within 64 KiB
@@ -300,9 +341,10 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         delete p;
         return RSPT_HIP_ERR_LAUNCH;
     }
-    CrcConsts cc;
+    static CrcConsts cc;  // ~87 KB: keep it off the stack
     make_crc_consts(cc);
-    if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess) {
+    if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&p->stamps, 512 * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
     }
@@ -356,6 +398,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     free_workspace(p);
     hipFree(p->crc);
+    hipFree(p->stamps);
     hipFree(p->nb_state);
     hipFree(p->cos_tab);
     hipFree(p->cos_tab_t);
@@ -427,11 +470,12 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     if (xd) HIPCHK(p, hipMemsetAsync(p->needmask, 0, nblocks * sizeof(uint32_t), st));
     HIPCHK(p, hipMemsetAsync(p->nzflag, 0, nblocks * kMaxPlanes * g.nblk * sizeof(uint32_t), st));
+    uint32_t np = 4;
     switch (g.bps) {
-        case 1: launch_front<1>(p, src, nblocks, st); break;
-        case 2: launch_front<2>(p, src, nblocks, st); break;
-        case 3: launch_front<3>(p, src, nblocks, st); break;
-        default: launch_front<4>(p, src, nblocks, st); break;
+        case 1: np = launch_front<1>(p, src, nblocks, st); break;
+        case 2: np = launch_front<2>(p, src, nblocks, st); break;
+        case 3: np = launch_front<3>(p, src, nblocks, st); break;
+        default: np = launch_front<4>(p, src, nblocks, st); break;
     }
     if (g.kind == RSPT_HIP_KIND_HADAMARD) {
         // per channel: mean removal, WHT, truncating /n (signal_packer_hadamard.cpp:57-72)
@@ -448,6 +492,14 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
 
     stamp(p, ST_NB, st);
     hipLaunchKernelGGL(k_nb_scan, dim3(1), dim3(1024), 0, st, p->needmask, B, p->nb_state, p->nbuse, xd ? 1 : 0);
+    if (xd && np < 4) {  // nb may have escalated in this call: add the planes the main pass did not write
+        switch (g.bps) {
+            case 1: launch_fixup<1>(p, src, nblocks, np, st); break;
+            case 2: launch_fixup<2>(p, src, nblocks, np, st); break;
+            case 3: launch_fixup<3>(p, src, nblocks, np, st); break;
+            default: launch_fixup<4>(p, src, nblocks, np, st); break;
+        }
+    }
 
     stamp(p, ST_HIST, st);
     hipLaunchKernelGGL(k_hist, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist);
@@ -461,10 +513,28 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
                        d_sizes);
 
     stamp(p, ST_ENCODE, st);
-    hipLaunchKernelGGL(k_encode, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->meta, p->cw, p->tdesc,
-                       p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride);
+    hipLaunchKernelGGL(k_encode, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->meta, p->cw, p->tdesc,
+                       p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps);
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks) {
+    if (!p) return 0;
+    return 32 + 16 * nblocks + nblocks * ((rspt_hip_max_compressed_size(p) + 15) & ~(size_t)15);
+}
+
+int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_stride, const uint64_t* d_sizes, size_t nblocks, void* d_packed,
+                            uint64_t* d_total, void* stream) {
+    if (!p || !d_dst || !d_sizes || !d_packed || !d_total || nblocks == 0 || nblocks > 65535) return RSPT_HIP_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_dst) & 15) || (dst_stride & 15) || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_pack_index, dim3(1), dim3(1024), 0, st, d_sizes, (uint32_t)nblocks, p->nb_state, (uint8_t*)d_packed, d_total);
+    hipLaunchKernelGGL(k_pack_copy, dim3(32, (unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)d_dst, (uint64_t)dst_stride, (uint32_t)nblocks,
+                       (uint8_t*)d_packed);
     HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
 }
@@ -484,6 +554,7 @@ unsigned rspt_hip_current_nb(rspt_hip_packer* p) {
     hipDeviceSynchronize();
     uint32_t nb = 0;
     if (hipMemcpy(&nb, p->nb_state, sizeof(nb), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    if (nb >= 1 && nb <= 4) p->nb_host = nb;
     return nb;
 }
 
@@ -494,6 +565,7 @@ int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb) {
     HIPCHK(p, hipDeviceSynchronize());
     uint32_t v = nb;
     HIPCHK(p, hipMemcpy(p->nb_state, &v, sizeof(v), hipMemcpyHostToDevice));
+    p->nb_host = nb;
     return RSPT_HIP_OK;
 }
 
@@ -523,8 +595,11 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
     rc = rspt_hip_compress_batch_dev(p, p->h_src, 1, p->h_dst, p->h_dst_cap, p->h_size, (void*)p->stream);
     if (rc) return rc;
     uint64_t sz = 0;
+    uint32_t nb_now = 0;
     HIPCHK(p, hipMemcpyAsync(&sz, p->h_size, sizeof(sz), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(p, hipMemcpyAsync(&nb_now, p->nb_state, sizeof(nb_now), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(p, hipStreamSynchronize(p->stream));
+    if (nb_now >= 1 && nb_now <= 4) p->nb_host = nb_now;  // the next call writes exactly the planes it needs
     if (sz >> 63) return RSPT_HIP_ERR_DST_TOO_SMALL;
     if (sz > dst_max_len) {
         *dst_len = (size_t)sz;
@@ -629,6 +704,7 @@ long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, siz
         case 4: src = p->meta; n = nhb * sizeof(BlockMeta); break;
         case 5: src = p->nbuse; n = p->cap_blocks * 4; break;
         case 6: src = p->means; n = p->cap_blocks * (size_t)g.hdr_len; break;
+        case 7: src = p->stamps; n = 512 * 16 * 8 * sizeof(unsigned long long); break;
         default: return RSPT_HIP_ERR_ARG;
     }
     if (!src || n == 0) return 0;

@@ -1,0 +1,102 @@
+"""The N>1 host path on CPU: world_size 2 over gloo.  Each rank takes its contiguous
+block range, produces streams (with the oracle as the stand-in compressor -- test
+infrastructure), packs them into a container and the containers are gathered to
+rank 0 exactly as bench.py does over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from rspt_amd import shard  # noqa: E402
+
+NCH, NS, BPS, NBLOCKS = 3, 700, 4, 7
+
+
+def _blocks():
+    import cases
+
+    return [cases._rand_native(NCH, NS, BPS, 800 + i, [50, 1 << 14, 60][i % 3], walk=bool(i & 1)) for i in range(NBLOCKS)]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from oracle.oracle import Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, count = shard.shard_range(NBLOCKS, rank, world)
+    orc = Oracle()
+    pk = orc.packer("xdelta_hzr", BPS, NCH, NS, 1)
+    blocks = _blocks()[first : first + count]
+    streams = [pk.compress(b) for b in blocks]
+    cont = shard.pack_container(streams, orc.packer_nb(pk))
+    packed = torch.frombuffer(bytearray(cont), dtype=torch.uint8)
+    total = torch.tensor([len(cont)], dtype=torch.int64)
+    got = shard.gather_containers(packed, total, dst=0)
+    if rank == 0:
+        q.put([bytes(t[:n].numpy().tobytes()) for t, n in got])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    for n in (1, 7, 64, 1024, 1000):
+        for w in (1, 2, 3, 8):
+            spans = [shard.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (a, ca), (b2, _) in zip(spans, spans[1:]):
+                assert a + ca == b2
+
+
+def test_container_roundtrip():
+    streams = [b"", b"x", bytes(range(40)), b"\xff" * 16]
+    c = shard.pack_container(streams, 3)
+    out, nb = shard.unpack_container(c)
+    assert out == streams and nb == 3
+    with pytest.raises(ValueError):
+        shard.unpack_container(b"\0" * 64)
+
+
+def test_gather_world2_gloo():
+    from oracle.oracle import Oracle
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    conts = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # rank order == block order; each rank's packer escalates on its own (one instance per rank)
+    orc = Oracle()
+    blocks = _blocks()
+    pos = 0
+    for r, c in enumerate(conts):
+        streams, nb = shard.unpack_container(c)
+        first, count = shard.shard_range(NBLOCKS, r, 2)
+        assert first == pos and len(streams) == count
+        pk = orc.packer("xdelta_hzr", BPS, NCH, NS, 1)
+        want = [pk.compress(b) for b in blocks[first : first + count]]
+        assert streams == want and nb == orc.packer_nb(pk)
+        # and they decode back with a decoder configured from the container's nb
+        dec = orc.packer("xdelta_hzr", BPS, NCH, NS, nb)
+        for s_, b in zip(streams[-1:], blocks[first + count - 1 : first + count]):
+            assert dec.decompress(s_)[0] == b.tobytes()
+        pos += count
+    assert pos == NBLOCKS

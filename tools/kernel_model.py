@@ -303,10 +303,17 @@ def granule_tokens_v2(block):
     out = []
     for g in range(len(nv)):
         lits, starts = granule_masks(zm[g], nv[g], zb[g])
+        # v3 refinement: run tokens of length 1 / 2 carry no extra bits and are looked up like
+        # literals (symbol 0 = byte value 0; symbol 256 for two zeros)
+        ze = zm[g] | ((1 << nv[g]) if za[g] >= 1 else 0) | ((2 << nv[g]) if za[g] >= 2 else 0)
+        len1 = starts & ~(ze >> 1)
+        two = starts & (ze >> 1) & ~(ze >> 2)
+        single, runs = lits | len1 | two, starts & ~(len1 | two)
+        assert single & runs == 0
         for i in range(nv[g]):
-            if (lits >> i) & 1:
-                out.append((int(block[16 * g + i]), 0, 0))
-            elif (starts >> i) & 1:
+            if (single >> i) & 1:
+                out.append((256 if (two >> i) & 1 else int(block[16 * g + i]), 0, 0))
+            elif (runs >> i) & 1:
                 ahead = _ctz(((~(zm[g] >> i)) & 0xFFFFFFFF) | (1 << (nv[g] - i)))
                 rem = ahead + (za[g] if i + ahead == nv[g] else 0)
                 out.append(run_symbol(min(CAP, rem)))
