@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
 __global__ __launch_bounds__(64) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g, const uint32_t* __restrict__ nb_state,
                                                  const uint64_t* __restrict__ blk_off, uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed) {
     __shared__ DecLds d;
-    const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
+    const uint32_t k = blockIdx.x, j = blockIdx.y, b = blockIdx.z;  // plane fastest: see k_encode
     if (k >= *nb_state) return;
     const uint32_t l = threadIdx.x;
     const uint32_t hb = hb_index(g, b, k, j);

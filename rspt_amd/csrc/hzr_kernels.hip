@@ -163,34 +163,59 @@ __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t 
     }
 }
 
-__global__ __launch_bounds__(kEncThreads) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist) {
+// Work distribution for k_hist / k_encode.  The hardware places workgroup i on XCD i % 8 and,
+// inside the XCD, walks the CUs round-robin; a grid in which heavy (plane 0) and light
+// workgroups alternate with a period that divides 256 parks the heavy ones on a fraction of
+// the CUs (measured: 117 of 512 slots busy, profiles/r01_notes.md).  So both kernels are
+// persistent: 2 workgroups per CU pull hzr-block indices from a counter until none are left.
+struct WorkItem {
+    uint32_t b, k, j;
+};
+__device__ __forceinline__ bool next_work(uint32_t* counter, uint32_t total, const Geom& g, uint32_t* s_slot, WorkItem& wi) {
+    __syncthreads();  // everyone is done with the previous block (and with *s_slot)
+    if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t v = *s_slot;
+    if (v >= total) return false;
+    wi.k = v % kMaxPlanes;  // plane fastest
+    wi.j = (v / kMaxPlanes) % g.nblk;
+    wi.b = v / (kMaxPlanes * g.nblk);
+    return true;
+}
+
+__global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist, uint32_t* __restrict__ counter,
+                                                     uint32_t total) {
     __shared__ uint32_t s_hist[kSymStride];
     __shared__ uint32_t s_scr[2 * kEncWaves];
-    const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
-    const uint32_t hb = hb_index(g, b, k, j);
-    const uint32_t nbu = nbuse[b];
-    const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
-    if (k >= nbu) return;
-    if (!segmask) return;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
+    __shared__ uint32_t s_slot;
     const uint32_t tid = threadIdx.x;
-    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-    if (tid < kSymStride) s_hist[tid] = 0;
-    LaneBlock L;
-    load_and_chain(in, in_size, segmask, L, s_scr);  // contains the barrier that publishes the zeroed histogram
-    if (wave_may_have_tokens(segmask, L)) {
-        GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
+    WorkItem wi;
+    while (next_work(counter, total, g, &s_slot, wi)) {
+        const uint32_t j = wi.j, k = wi.k, b = wi.b;
+        const uint32_t hb = hb_index(g, b, k, j);
+        const uint32_t nbu = nbuse[b];
+        const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
+        if (k >= nbu) continue;
+        if (!segmask) continue;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
+        const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+        const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+        if (tid < kSymStride) s_hist[tid] = 0;
+        LaneBlock L;
+        load_and_chain(in, in_size, segmask, L, s_scr);  // contains the barrier that publishes the zeroed histogram
+        if (wave_may_have_tokens(segmask, L)) {
+            GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
 #pragma unroll 1
-        for (int r = 0; r < 4; ++r) {
-            hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
+            for (int r = 0; r < 4; ++r) {
+                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
+                q0 = q1;
+                q1 = q2;
+                q2 = q3;
+            }
         }
+        __syncthreads();
+        if (tid < kSymStride) hist[(size_t)hb * kSymStride + tid] = s_hist[tid];
     }
-    __syncthreads();
-    if (tid < kSymStride) hist[(size_t)hb * kSymStride + tid] = s_hist[tid];
 }
 
 // ===========================================================================
@@ -574,26 +599,29 @@ __device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo) {
 
 // `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
 // emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
-__global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                       const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
-                                                       const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
-                                                       const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
-                                                       uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate,
-                                                       unsigned long long* __restrict__ stamps) {
-    __shared__ EncLds d;
-    // diagnostic (ablate bit 7): lane 0 of every wave of the first 512 hzr blocks stores s_memtime at section seams
+__device__ __forceinline__ void encode_block(EncLds& d, uint32_t b, uint32_t k, uint32_t j, const uint8_t* __restrict__ planes, const Geom& g,
+                                             const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
+                                             const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
+                                             const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
+                                             uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate,
+                                             unsigned long long* __restrict__ stamps) {
+    // diagnostic (ablate bit 7): lane 0 of every wave of 512 hzr blocks (window ablate>>16) stores s_memtime at section seams
 #define RSPT_STAMP(i)                                                                                      \
     do {                                                                                                   \
-        if ((ablate & 128u) && (threadIdx.x & 63u) == 0 && hb_index(g, blockIdx.z, blockIdx.y, blockIdx.x) < 512u) \
-            stamps[(hb_index(g, blockIdx.z, blockIdx.y, blockIdx.x) * 16u + (threadIdx.x >> 6)) * 8u + (i)] = __builtin_amdgcn_s_memtime();      \
+        const uint32_t hb_ = hb_index(g, b, k, j) - (ablate >> 16) * 512u;                \
+        if ((ablate & 128u) && (threadIdx.x & 63u) == 0 && hb_ < 512u)                                                 \
+            stamps[(hb_ * 16u + (threadIdx.x >> 6)) * 8u + (i)] = __builtin_amdgcn_s_memtime();                        \
     } while (0)
-    const uint32_t j = blockIdx.x, k = blockIdx.y, b = blockIdx.z;
     const uint32_t hb = hb_index(g, b, k, j);
     // three independent loads in one round trip (their addresses depend on the block index only)
     const BlockMeta m = meta[hb];
     const uint64_t off = out_off[hb];
     const uint32_t segmask = nzflag[hb];
+    // diagnostic (ablate bit 8): wall-clock (100 MHz) start/end of every workgroup, for a concurrency census
+    if ((ablate & 256u) && threadIdx.x == 0 && hb < 16384u) stamps[65536u + 2u * hb] = __builtin_amdgcn_s_memrealtime();
     if (m.mode == kModeSkip || (ablate & 16u)) return;  // plane not used by this block (k >= nb)
+    if ((ablate & 4096u) && m.payload_len < 256u) return;   // timing probe: small blocks cost nothing
+    if ((ablate & 8192u) && m.payload_len >= 256u) return;  // timing probe: large blocks cost nothing
     if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
     const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     uint8_t* o = dst + (size_t)b * dst_stride + off;
@@ -625,11 +653,6 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
     const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     const uint32_t L = m.payload_len;
     RSPT_STAMP(0);
-    {
-        const uint32_t* t = &cc->table[0][0];
-        uint32_t* dt = &d.crc[0][0];
-        dt[tid] = t[tid];  // 1024 threads, 4 x 256 entries
-    }
 
     if (m.mode == kModeHuff) {
         // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
@@ -756,7 +779,22 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         pw[i] = __builtin_amdgcn_alignbyte(d.stage[skew(i + 2)], d.stage[skew(i + 1)], head);
     }
     RSPT_STAMP(7);
+    if ((ablate & 256u) && threadIdx.x == 0 && hb < 16384u) stamps[65536u + 2u * hb + 1u] = __builtin_amdgcn_s_memrealtime();
 #undef RSPT_STAMP
+}
+
+__global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+                                                          const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
+                                                          const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
+                                                          const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                                          uint32_t ablate, unsigned long long* __restrict__ stamps, uint32_t* __restrict__ counter,
+                                                          uint32_t total) {
+    __shared__ EncLds d;
+    __shared__ uint32_t s_slot;
+    (&d.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
+    WorkItem wi;
+    while (next_work(counter, total, g, &s_slot, wi))
+        encode_block(d, wi.b, wi.k, wi.j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps);
 }
 
 // ===========================================================================

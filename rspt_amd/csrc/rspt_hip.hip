@@ -107,6 +107,8 @@ struct rspt_hip_packer {
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
+    uint32_t* work_ctr = nullptr;  // [2] work counters of the persistent k_hist / k_encode (zeroed per call)
+    int num_cu = 256;
     uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte
     uint32_t* nb_state = nullptr;  // [1] persistent
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
@@ -343,8 +345,10 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     }
     static CrcConsts cc;  // ~87 KB: keep it off the stack
     make_crc_consts(cc);
+    p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&p->stamps, 512 * 16 * 8 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&p->work_ctr, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
     }
@@ -398,6 +402,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     free_workspace(p);
     hipFree(p->crc);
+    hipFree(p->work_ctr);
     hipFree(p->stamps);
     hipFree(p->nb_state);
     hipFree(p->cos_tab);
@@ -470,6 +475,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     if (xd) HIPCHK(p, hipMemsetAsync(p->needmask, 0, nblocks * sizeof(uint32_t), st));
     HIPCHK(p, hipMemsetAsync(p->nzflag, 0, nblocks * kMaxPlanes * g.nblk * sizeof(uint32_t), st));
+    HIPCHK(p, hipMemsetAsync(p->work_ctr, 0, 2 * sizeof(uint32_t), st));
     uint32_t np = 4;
     switch (g.bps) {
         case 1: np = launch_front<1>(p, src, nblocks, st); break;
@@ -502,10 +508,11 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     }
 
     stamp(p, ST_HIST, st);
-    hipLaunchKernelGGL(k_hist, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist);
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
+    const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
+    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->work_ctr, nhb);
 
     stamp(p, ST_TREE, st);
-    const uint32_t nhb = B * kMaxPlanes * g.nblk;
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta);
 
     stamp(p, ST_LAYOUT, st);
@@ -513,8 +520,8 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
                        d_sizes);
 
     stamp(p, ST_ENCODE, st);
-    hipLaunchKernelGGL(k_encode, dim3(g.nblk, kMaxPlanes, B), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->meta, p->cw, p->tdesc,
-                       p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps);
+    hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
+                       (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, p->work_ctr + 1, nhb);
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
@@ -624,7 +631,7 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
         HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
                            d_consumed, p->means);
-        hipLaunchKernelGGL(k_dec_block, dim3(g.nblk, kMaxPlanes, B), dim3(64), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
+        hipLaunchKernelGGL(k_dec_block, dim3(kMaxPlanes, g.nblk, B), dim3(64), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
                            d_consumed);
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
@@ -704,7 +711,7 @@ long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, siz
         case 4: src = p->meta; n = nhb * sizeof(BlockMeta); break;
         case 5: src = p->nbuse; n = p->cap_blocks * 4; break;
         case 6: src = p->means; n = p->cap_blocks * (size_t)g.hdr_len; break;
-        case 7: src = p->stamps; n = 512 * 16 * 8 * sizeof(unsigned long long); break;
+        case 7: src = p->stamps; n = (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long); break;
         default: return RSPT_HIP_ERR_ARG;
     }
     if (!src || n == 0) return 0;

@@ -1,7 +1,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-os.environ["RSPT_ABLATE"] = "128"
+WIN = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+os.environ["RSPT_ABLATE"] = str(128 + (WIN << 16))
 from rspt_amd import api, synth
 B = 64
 pk = api.new_xdelta_hzr(4, 64, 65536, 3)
@@ -21,7 +22,7 @@ for label, sel in (("plane0 blocks (dense)", [i for i in range(512) if (i // 64)
         print("   %-24s median %8.0f  mean %8.0f  max %8.0f cycles" % (n, np.median(v), v.mean(), v.max()))
     tot = (s[:, :, 7] - s[:, :, 0])[ok]
     print("   total per wave median %.0f cycles; block span median %.0f" % (np.median(tot), np.median(s[:, :, 7].max(axis=1) - s[:, :, 0].min(axis=1))))
-for blk in (64, 65, 0):
+for blk in (64, 0):
     s = st[blk]
     print("block", blk, "per-wave section cycles (rows = waves):")
     print(np.diff(s, axis=1) if False else np.diff(s, axis=1).astype(int))
