@@ -140,11 +140,17 @@ __device__ __forceinline__ bool wave_may_have_tokens(uint32_t segmask, const Lan
 // tokens by iterating over the `starts` mask.  The callers walk a lane's four
 // granules with a rolled loop that rotates them through one register set, so the
 // body exists once (instruction-cache footprint) and still uses ds_ instructions.
-struct GranuleRegs {
-    uint32_t w0, w1, w2, w3, nv, zm, zb, za;
+struct GranuleRegs {  // packed to keep four of them live at the 64-VGPR budget
+    uint32_t w0, w1, w2, w3;
+    uint32_t nvzm;  // zm | nv << 16
+    uint32_t zbza;  // zb | za << 16   (both <= 65520)
+    __device__ __forceinline__ uint32_t nv() const { return nvzm >> 16; }
+    __device__ __forceinline__ uint32_t zm() const { return nvzm & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t zb() const { return zbza & 0xFFFFu; }
+    __device__ __forceinline__ uint32_t za() const { return zbza >> 16; }
 };
 __device__ __forceinline__ GranuleRegs granule_regs(const LaneBlock& L, int r) {
-    return GranuleRegs{L.g[r].w[0], L.g[r].w[1], L.g[r].w[2], L.g[r].w[3], L.g[r].nv, L.g[r].zm, L.zb[r], L.za[r]};
+    return GranuleRegs{L.g[r].w[0], L.g[r].w[1], L.g[r].w[2], L.g[r].w[3], L.g[r].zm | (L.g[r].nv << 16), L.zb[r] | (L.za[r] << 16)};
 }
 __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
                                           uint32_t za, uint32_t* s_hist) {
@@ -171,9 +177,9 @@ __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t 
 struct WorkItem {
     uint32_t b, k, j;
 };
-__device__ __forceinline__ bool next_work(uint32_t* counter, uint32_t total, const Geom& g, uint32_t* s_slot, WorkItem& wi) {
+__device__ __forceinline__ bool next_work(uint32_t* counter, uint32_t total, const Geom& g, uint32_t* s_slot, WorkItem& wi, uint32_t pass) {
     __syncthreads();  // everyone is done with the previous block (and with *s_slot)
-    if (threadIdx.x == 0) *s_slot = atomicAdd(counter, 1u);
+    if (threadIdx.x == 0) *s_slot = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(counter, 1u);  // first item static
     __syncthreads();
     const uint32_t v = *s_slot;
     if (v >= total) return false;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
     __shared__ uint32_t s_slot;
     const uint32_t tid = threadIdx.x;
     WorkItem wi;
-    while (next_work(counter, total, g, &s_slot, wi)) {
+    for (uint32_t pass = 0; next_work(counter, total, g, &s_slot, wi, pass); ++pass) {
         const uint32_t j = wi.j, k = wi.k, b = wi.b;
         const uint32_t hb = hb_index(g, b, k, j);
         const uint32_t nbu = nbuse[b];
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
             GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
-                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, s_hist);
+                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), s_hist);
                 q0 = q1;
                 q1 = q2;
                 q2 = q3;
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         bits_sum += h[sym] * (len + run_extra_bits(sym));
     }
     bits_sum = wave_add_u32(bits_sum);
+    const uint32_t ntok = wave_add_u32(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4]);
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         const uint32_t nbytes = (total_bits + 7) >> 3;
         // Huffman iff the payload fits in in_size bytes and is < 65536 (hzr_encode.c:377-382,463-469)
         if (nbytes <= in_size && nbytes < kHzrBlock)
-            meta[hb] = BlockMeta{kModeHuff, nbytes, tree_bits, 0};
+            meta[hb] = BlockMeta{kModeHuff, nbytes, tree_bits, ntok};  // (fill is unused in this mode: it carries the token count)
         else
             meta[hb] = BlockMeta{kModeCopy, in_size, 0, 0};
     }
@@ -395,9 +402,23 @@ __device__ __forceinline__ void store_le32(uint8_t* p, uint32_t v) {
     p[3] = (uint8_t)(v >> 24);
 }
 
+// It also sorts the hzr blocks into the work queues of k_encode: Fill blocks (8 bytes) are written
+// right here; Huffman blocks with few tokens and a small payload go to the `small` queue (one WAVE encodes one such
+// block), everything else to the `big` queue (one 1024-thread workgroup per block).
+constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
+constexpr uint32_t kSmallTokens = 512;    // a single wave walks the block row by row: only worth it for few tokens ...
+constexpr uint32_t kSmallSegments = 2;    // ... in few non-zero 4 KiB segments (each costs one dependent HBM round trip)
+
+struct WorkQueues {
+    uint32_t n_big, n_small;      // filled by k_layout
+    uint32_t next_big, next_small;  // consumed by k_encode
+};
+
 __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restrict__ nbuse, const BlockMeta* __restrict__ meta,
                                                const uint8_t* __restrict__ means_hdr, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                               uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes) {
+                                               uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes, const CrcConsts* __restrict__ cc,
+                                               const uint32_t* __restrict__ nzflag, WorkQueues* __restrict__ wq,
+                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list) {
     __shared__ uint64_t s_part[256];
     __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
@@ -441,6 +462,27 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
         return;
     }
     uint8_t* o = dst + (size_t)b * dst_stride;
+    for (uint32_t q = lo; q < hi; ++q) {
+        const BlockMeta m = meta[hb0 + q];
+        if (m.mode == kModeFill) {  // EncodeFill (hzr_encode.c:341-367): [00 00][crc32c(value)][02][value]
+            uint8_t* f = o + out_off[hb0 + q];
+            uint32_t c = 0xFFFFFFFFu ^ m.fill;
+            c = ~((c >> 8) ^ cc->table[0][c & 0xFFu]);
+            f[0] = 0;
+            f[1] = 0;
+            f[2] = (uint8_t)c;
+            f[3] = (uint8_t)(c >> 8);
+            f[4] = (uint8_t)(c >> 16);
+            f[5] = (uint8_t)(c >> 24);
+            f[6] = (uint8_t)kModeFill;
+            f[7] = (uint8_t)m.fill;
+        } else if (m.mode == kModeHuff && m.payload_len <= kSmallPayload && m.fill <= kSmallTokens &&
+                   __popc(nzflag[hb0 + q]) <= (int)kSmallSegments) {
+            small_list[atomicAdd(&wq->n_small, 1u)] = hb0 + q;
+        } else if (m.mode == kModeHuff || m.mode == kModeCopy) {
+            big_list[atomicAdd(&wq->n_big, 1u)] = hb0 + q;
+        }
+    }
     if (tid == 0) o[0] = (uint8_t)g.method;  // signal_packer_base.cpp:83
     for (uint32_t i = tid; i < g.hdr_len; i += 256) o[1 + i] = means_hdr[(size_t)b * g.hdr_len + i];  // :86-91
     if (tid < nb) {
@@ -500,6 +542,12 @@ struct BitSink {
         if (n) atomicOr(&stage[skew(word)], lo);
     }
 };
+
+// byte i (dynamic) of a granule held in four registers
+__device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
+    const uint32_t lo = (i & 8u) ? w2 : w0, hi = (i & 8u) ? w3 : w1;
+    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (i & 7u));  // byte (i & 7) of {hi,lo}, zero-extended
+}
 
 // pass 1: number of stream bits of the tokens that start in this granule
 __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
@@ -599,12 +647,20 @@ __device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo) {
 
 // `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
 // emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
-__device__ __forceinline__ void encode_block(EncLds& d, uint32_t b, uint32_t k, uint32_t j, const uint8_t* __restrict__ planes, const Geom& g,
+// The workgroup-per-block encoder's LDS lives at namespace scope so that encode_block can be a
+// real (not inlined) function and still address it with ds_ instructions: inlined into the
+// persistent loop it spilled ~55 registers per lane at the 64-VGPR budget of two workgroups per CU.
+__shared__ EncLds g_enc;
+
+template <bool DIAG>
+__device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j, const uint8_t* __restrict__ planes, const Geom& g,
                                              const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
                                              const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                              const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
-                                             uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate,
+                                             uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate_arg,
                                              unsigned long long* __restrict__ stamps) {
+    EncLds& d = g_enc;
+    const uint32_t ablate = DIAG ? ablate_arg : 0u;  // the production instantiation carries no diagnostic code
     // diagnostic (ablate bit 7): lane 0 of every wave of 512 hzr blocks (window ablate>>16) stores s_memtime at section seams
 #define RSPT_STAMP(i)                                                                                      \
     do {                                                                                                   \
@@ -670,7 +726,7 @@ __device__ __forceinline__ void encode_block(EncLds& d, uint32_t b, uint32_t k, 
         uint32_t nbits[4] = {0, 0, 0, 0};
 #pragma unroll 1
         for (int r = 0; r < 4 && active; ++r) {  // rolled: granules and results rotate through fixed registers
-            const uint32_t nbv = (ablate & 4u) ? 100u : bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw);
+            const uint32_t nbv = (ablate & 4u) ? 100u : bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw);
             const GranuleRegs t = q0;
             q0 = q1;
             q1 = q2;
@@ -700,7 +756,7 @@ __device__ __forceinline__ void encode_block(EncLds& d, uint32_t b, uint32_t k, 
         uint32_t nz0 = nbits[0], nz1 = nbits[1], nz2 = nbits[2], nz3 = nbits[3];
 #pragma unroll 1
         for (int r = 0; r < 4 && active; ++r) {  // after four rotations q0..q3 are back in order
-            if (nz0 && !(ablate & 1u)) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv, q0.zm, q0.zb, q0.za, d.cw, d.stage, pos0);
+            if (nz0 && !(ablate & 1u)) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.stage, pos0);
             q0 = q1;
             q1 = q2;
             q2 = q3;
@@ -783,18 +839,286 @@ __device__ __forceinline__ void encode_block(EncLds& d, uint32_t b, uint32_t k, 
 #undef RSPT_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small blocks: one WAVE encodes one hzr block, 16 blocks per workgroup pass, no workgroup barrier.
+// The wave streams over the block's rows in order, so it needs only forward information: every
+// zero run is emitted when it ENDS, right before the literal that ends it (or at the block end),
+// as floor(R/16662) capped tokens plus a remainder token -- the same token sequence as the
+// reference's greedy walk (hzr_encode.c:410-457).  Zero 4 KiB segments are skipped without a read.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSlotWords = kStagePhys / kEncWaves;  // per-wave LDS slot: [cw 264][image]
+constexpr uint32_t kSlotImage = kSlotWords - kSymStride;  // words of X || payload (+ slack)
+static_assert(kSlotImage * 4 >= kSmallPayload + 4 + 72, "small-block slot too small");
+
+struct LinSink {  // BitSink on a linear (unskewed) image
+    uint32_t* img;
+    uint32_t lo, n, word;
+    __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
+        img = s;
+        lo = 0;
+        n = bitpos & 31u;
+        word = bitpos >> 5;
+    }
+    __device__ __forceinline__ void put(uint32_t v, uint32_t len) {
+        lo |= v << n;
+        const uint32_t tot = n + len;
+        if (tot >= 32) {
+            atomicOr(&img[word], lo);
+            ++word;
+            lo = (v >> 1) >> (31u - n);
+            n = tot - 32;
+        } else {
+            n = tot;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (n) atomicOr(&img[word], lo);
+    }
+};
+
+// stream bits of the tokens of a zero run of length R (0 < R): capped tokens, then the remainder
+__device__ __forceinline__ uint32_t run_bits(const uint32_t* cwt, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    uint32_t bits = q * ((cwt[260] >> 24) + 14u);
+    if (rem) {
+        const uint32_t sym = run_symbol(rem);
+        bits += (cwt[sym] >> 24) + run_extra_bits(sym);
+    }
+    return bits;
+}
+
+template <typename Sink>
+__device__ __forceinline__ void run_emit(Sink& sink, const uint32_t* cwt, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    for (uint32_t i = 0; i < q; ++i) {
+        const uint32_t c = cwt[260];
+        sink.put(c & 0x00FFFFFFu, c >> 24);
+        sink.put(kRunCap - 279u, 14);
+    }
+    if (rem) {
+        const uint32_t sym = run_symbol(rem);
+        const uint32_t c = cwt[sym];
+        sink.put(c & 0x00FFFFFFu, c >> 24);
+        const uint32_t eb = run_extra_bits(sym);
+        if (eb) sink.put(run_extra_value(sym, rem), eb);
+    }
+}
+
+__device__ __forceinline__ uint32_t crc_chunk64_lin(const uint32_t* img, const uint32_t (*tab)[256], int32_t lo) {
+    const int32_t a = lo >> 2;
+    const uint32_t sh = (uint32_t)lo & 3u;
+    uint32_t c = 0;
+    uint32_t prev = a >= 0 ? img[a] : 0u;
+#pragma unroll
+    for (int32_t q = 0; q < 16; ++q) {
+        const int32_t ix = a + q + 1;
+        const uint32_t next = ix >= 0 ? img[ix] : 0u;
+        c ^= __builtin_amdgcn_alignbyte(next, prev, sh);
+        prev = next;
+        c = tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+    }
+    return c;
+}
+
+__device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img, const uint32_t (*crc_tab)[256], uint32_t hb,
+                                                   const uint8_t* __restrict__ planes, const Geom& g,
+                                                   const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
+                                                   const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
+                                                   const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
+                                                   uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate) {
+    const uint32_t l = lane_id();
+    if (ablate & 512u) return;
+    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    const BlockMeta m = meta[hb];
+    const uint64_t off = out_off[hb];
+    const uint32_t segmask = nzflag[hb];
+    if (off == ~0ull) return;
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    const uint32_t L = m.payload_len;
+    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) cwt[i] = cw[(size_t)hb * kSymStride + i];
+    for (uint32_t i = l; i < kSlotImage; i += 64) img[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (l == 0) img[0] = cc->prefix;
+    const uint32_t twords = (m.tree_bits + 31) >> 5;
+    for (uint32_t i = l; i < twords; i += 64) atomicOr(&img[1 + i], tdesc[(size_t)hb * kTdescWords + i]);
+
+    uint32_t pend = 0;                       // zeros pending in front of the current position (wave-uniform)
+    uint32_t bitpos = 32u + m.tree_bits;     // next stream bit (wave-uniform)
+    const unsigned long long lt = (1ull << l) - 1ull;
+    const uint32_t nseg = (in_size + 4095u) >> 12;
+    // One wave walks 64 rows in order, so HBM latency is hidden by reading a whole 4 KiB segment
+    // (4 rows) at once, one segment ahead of the one being processed.
+    uint4 cur[4], nxt[4];
+    auto issue = [&](uint32_t seg, uint4* buf) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t pos = (seg << 12) + (r << 10) + 16u * l;
+            buf[r] = make_uint4(0, 0, 0, 0);
+            if (seg < nseg && ((segmask >> seg) & 1u) && pos < in_size) buf[r] = *reinterpret_cast<const uint4*>(in + pos);
+        }
+    };
+    issue(0, cur);
+    for (uint32_t seg = 0; seg < nseg && !(ablate & 1024u); ++seg) {
+        issue(seg + 1, nxt);
+        const uint32_t seg_base = seg << 12;
+        if (!((segmask >> seg) & 1u)) {
+            pend += min(4096u, in_size - seg_base);
+        } else {
+#pragma unroll
+            for (uint32_t r = 0; r < 4; ++r) {
+                const uint32_t base = seg_base + (r << 10);
+                if (base < in_size) {
+                    const uint32_t row_valid = min(1024u, in_size - base);
+                    Granule gr;
+                    const uint32_t pos = base + 16u * l;
+                    gr.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
+                    gr.w[0] = cur[r].x;
+                    gr.w[1] = cur[r].y;
+                    gr.w[2] = cur[r].z;
+                    gr.w[3] = cur[r].w;
+                    granule_finish(gr);
+                    const uint32_t lits = ~gr.zm & ((1u << gr.nv) - 1u);
+                    const unsigned long long nzb = __ballot(lits != 0);
+                    if (!nzb) {
+                        pend += row_valid;
+                    } else {
+                        // zeros in front of this granule: the nearest lower lane with a literal closes the run
+                        const uint32_t last_nz = lits ? 31u - (uint32_t)__builtin_clz(lits) : 0u;  // index of the granule's last literal
+                        const uint32_t trail = lits ? (15u - last_nz) : 16u;                         // zeros behind it inside the (full) granule
+                        const unsigned long long below = nzb & lt;
+                        const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                        const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
+                        const uint32_t zb = below ? (16u * (l - 1u - p) + tp) : (16u * l + pend);
+                        // pass A: bits of this lane's tokens
+                        uint32_t nbits = 0;
+                        {
+                            uint32_t t = lits, prev_end = 0;  // prev_end = index after the previous literal
+                            bool first = true;
+                            while (t) {
+                                const uint32_t i = (uint32_t)__builtin_ctz(t);
+                                t &= t - 1;
+                                const uint32_t R = first ? (zb + i) : (i - prev_end);
+                                if (R) nbits += run_bits(cwt, R);
+                                nbits += cwt[granule_byte_dyn(gr.w[0], gr.w[1], gr.w[2], gr.w[3], i)] >> 24;
+                                prev_end = i + 1;
+                                first = false;
+                            }
+                        }
+                        const uint32_t inc = wave_scan_add(nbits);
+                        const uint32_t mypos = bitpos + inc - nbits;
+                        bitpos += (uint32_t)__shfl((int)inc, 63, 64);
+                        // pass B: emit
+                        if (nbits) {
+                            LinSink sink;
+                            sink.start(img, mypos);
+                            uint32_t t = lits, prev_end = 0;
+                            bool first = true;
+                            while (t) {
+                                const uint32_t i = (uint32_t)__builtin_ctz(t);
+                                t &= t - 1;
+                                const uint32_t R = first ? (zb + i) : (i - prev_end);
+                                if (R) run_emit(sink, cwt, R);
+                                const uint32_t c = cwt[granule_byte_dyn(gr.w[0], gr.w[1], gr.w[2], gr.w[3], i)];
+                                sink.put(c & 0x00FFFFFFu, c >> 24);
+                                prev_end = i + 1;
+                                first = false;
+                            }
+                            sink.flush();
+                        }
+                        // zeros behind the row's last literal stay pending
+                        const uint32_t pl = 63u - (uint32_t)__builtin_clzll(nzb);
+                        const uint32_t lastlit = (uint32_t)__shfl((int)last_nz, (int)pl, 64);
+                        pend = row_valid - (16u * pl + lastlit + 1u);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) cur[r] = nxt[r];
+    }
+    if (pend && l == 0) {  // the run that reaches the block end
+        LinSink sink;
+        sink.start(img, bitpos);
+        run_emit(sink, cwt, pend);
+        sink.flush();
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+
+    // CRC-32C of X || payload: lane l owns the 64-byte chunk (63 - l) counted from the end
+    const int32_t Lv = (int32_t)L + 4;
+    const int32_t hi = Lv - 64 * (int32_t)(63u - l);
+    uint32_t c = 0;
+    if (hi > 0 && !(ablate & 2048u)) c = crc_chunk64_lin(img, crc_tab, hi - 64);
+    const uint32_t crc = (ablate & 2048u) ? 0u : ~wave_xor_u32(gf_shift(cc, l, c));
+
+    uint8_t* o = dst + (size_t)b * dst_stride + off;
+    if (l == 0) {
+        o[0] = (uint8_t)(L - 1);
+        o[1] = (uint8_t)((L - 1) >> 8);
+        o[2] = (uint8_t)crc;
+        o[3] = (uint8_t)(crc >> 8);
+        o[4] = (uint8_t)(crc >> 16);
+        o[5] = (uint8_t)(crc >> 24);
+        o[6] = (uint8_t)kModeHuff;
+    }
+    const uint8_t* img8 = reinterpret_cast<const uint8_t*>(img) + 4;
+    for (uint32_t i = l; i < L; i += 64) o[7 + i] = img8[i];
+    __builtin_amdgcn_wave_barrier();  // the slot is reused by this wave's next block
+}
+
+template <bool DIAG>
 __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
                                                           const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                           const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                                          uint32_t ablate, unsigned long long* __restrict__ stamps, uint32_t* __restrict__ counter,
-                                                          uint32_t total) {
-    __shared__ EncLds d;
+                                                          uint32_t ablate, unsigned long long* __restrict__ stamps, WorkQueues* __restrict__ wq,
+                                                          const uint32_t* __restrict__ big_list) {
     __shared__ uint32_t s_slot;
-    (&d.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
-    WorkItem wi;
-    while (next_work(counter, total, g, &s_slot, wi))
-        encode_block(d, wi.b, wi.k, wi.j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps);
+    (&g_enc.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
+    const uint32_t n_big = wq->n_big;
+    // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
+    // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
+    for (uint32_t pass = 0;; ++pass) {
+        __syncthreads();  // everyone is done with the previous block (and with s_slot)
+        if (threadIdx.x == 0) s_slot = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(&wq->next_big, 1u);
+        __syncthreads();
+        const uint32_t i = s_slot;
+        if (i >= n_big) break;
+        const uint32_t hb = big_list[i];
+        const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps);
+    }
+}
+
+// small blocks: 4 waves per workgroup, each wave pulls blocks on its own (no workgroup barrier after the table load)
+constexpr int kSmallWaves = 4;
+__global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+                                                                  const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
+                                                                  const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
+                                                                  const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                                                  WorkQueues* __restrict__ wq, const uint32_t* __restrict__ small_list, uint32_t ablate) {
+    __shared__ uint32_t s_crc[4][256];
+    __shared__ uint32_t s_slot[kSmallWaves][kSlotWords];
+    for (uint32_t i = threadIdx.x; i < 1024; i += kSmallWaves * 64) (&s_crc[0][0])[i] = (&cc->table[0][0])[i];
+    __syncthreads();
+    const uint32_t n_small = wq->n_small;
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * kSmallWaves;
+    for (uint32_t pass = 0;; ++pass) {
+        uint32_t i = blockIdx.x * kSmallWaves + wv;  // first block: static
+        if (pass) {
+            if (lane_id() == 0) i = nwaves + atomicAdd(&wq->next_small, 1u);
+            i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        }
+        if (i >= n_small) break;
+        encode_small_block(s_slot[wv], s_slot[wv] + kSymStride, s_crc, small_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst,
+                           dst_stride, ablate);
+    }
 }
 
 // ===========================================================================

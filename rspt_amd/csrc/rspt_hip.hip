@@ -88,8 +88,8 @@ void make_crc_consts(CrcConsts& cc) {
     cc.pad[0] = cc.pad[1] = cc.pad[2] = 0;
 }
 
-enum Stage { ST_PRE = 0, ST_NB, ST_HIST, ST_TREE, ST_LAYOUT, ST_ENCODE, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"preprocess", "nb_scan", "hzr_hist", "hzr_tree", "layout", "hzr_encode"};
+enum Stage { ST_PRE = 0, ST_NB, ST_HIST, ST_TREE, ST_LAYOUT, ST_ENCODE, ST_ENCODE_SMALL, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"preprocess", "nb_scan", "hzr_hist", "hzr_tree", "layout", "hzr_encode", "hzr_encode_small"};
 
 }  // namespace
 
@@ -107,7 +107,9 @@ struct rspt_hip_packer {
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
-    uint32_t* work_ctr = nullptr;  // [2] work counters of the persistent k_hist / k_encode (zeroed per call)
+    uint32_t* work_ctr = nullptr;  // [1 + 4] work counter of the persistent k_hist, then the WorkQueues of k_encode (zeroed per call)
+    uint32_t* big_list = nullptr;  // [cap*4*nblk] hzr blocks for the workgroup-per-block encoder (filled by k_layout)
+    uint32_t* small_list = nullptr;  // [cap*4*nblk] hzr blocks for the wave-per-block encoder
     int num_cu = 256;
     uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte
     uint32_t* nb_state = nullptr;  // [1] persistent
@@ -228,7 +230,9 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->needmask);
     hipFree(p->nbuse);
     hipFree(p->nzflag);
-    p->nzflag = nullptr;
+    hipFree(p->big_list);
+    hipFree(p->small_list);
+    p->nzflag = p->big_list = p->small_list = nullptr;
     hipFree(p->hist);
     hipFree(p->cw);
     hipFree(p->tdesc);
@@ -347,7 +351,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     make_crc_consts(cc);
     p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&p->work_ctr, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(&p->work_ctr, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -439,6 +443,8 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->needmask, max_blocks * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->nzflag, nhb * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->cw, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->tdesc, nhb * kTdescWords * sizeof(uint32_t)) == hipSuccess;
@@ -475,7 +481,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     if (xd) HIPCHK(p, hipMemsetAsync(p->needmask, 0, nblocks * sizeof(uint32_t), st));
     HIPCHK(p, hipMemsetAsync(p->nzflag, 0, nblocks * kMaxPlanes * g.nblk * sizeof(uint32_t), st));
-    HIPCHK(p, hipMemsetAsync(p->work_ctr, 0, 2 * sizeof(uint32_t), st));
+    HIPCHK(p, hipMemsetAsync(p->work_ctr, 0, 8 * sizeof(uint32_t), st));
     uint32_t np = 4;
     switch (g.bps) {
         case 1: np = launch_front<1>(p, src, nblocks, st); break;
@@ -516,12 +522,24 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta);
 
     stamp(p, ST_LAYOUT, st);
+    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
-                       d_sizes);
+                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list);
 
     stamp(p, ST_ENCODE, st);
-    hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
-                       (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, p->work_ctr + 1, nhb);
+    if (p->ablate)
+        hipLaunchKernelGGL((k_encode<true>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, wq, p->big_list);
+    else
+        hipLaunchKernelGGL((k_encode<false>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, 0u, p->stamps, wq, p->big_list);
+    stamp(p, ST_ENCODE_SMALL, st);
+    {
+        const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
+        const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
+        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate);
+    }
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
@@ -711,6 +729,7 @@ long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, siz
         case 4: src = p->meta; n = nhb * sizeof(BlockMeta); break;
         case 5: src = p->nbuse; n = p->cap_blocks * 4; break;
         case 6: src = p->means; n = p->cap_blocks * (size_t)g.hdr_len; break;
+        case 8: src = p->nzflag; n = nhb * 4; break;
         case 7: src = p->stamps; n = (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long); break;
         default: return RSPT_HIP_ERR_ARG;
     }
