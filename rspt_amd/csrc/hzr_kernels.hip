@@ -120,6 +120,19 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
     __syncthreads();  // scratch may be reused by the caller
 }
 
+// byte i (dynamic) of a granule held in four registers
+__device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
+    const uint32_t lo = (i & 8u) ? w2 : w0, hi = (i & 8u) ? w3 : w1;
+    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (i & 7u));  // byte (i & 7) of {hi,lo}, zero-extended
+}
+
+// "Small" hzr blocks -- few non-zero 4 KiB segments -- are walked by ONE wave, row by row, instead of
+// by a 1024-thread workgroup: their histogram is taken inside k_tree (k_hist skips them) and, if they
+// also have few tokens and a small payload, they are encoded by k_encode_small.
+constexpr uint32_t kSmallSegments = 2;    // non-zero 4 KiB segments (each costs one dependent HBM round trip)
+constexpr uint32_t kSmallTokens = 512;    // tokens
+constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
+
 // A wave whose 4 KiB segment is all zero holds a token only where a zero-run token
 // starts: at the block start (no zeros before) or at a multiple of 16662 inside the
 // run (hzr_encode.c:149).  Wave-uniform, so whole waves skip their token loops.
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         const uint32_t nbu = nbuse[b];
         const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
         if (k >= nbu) continue;
-        if (!segmask) continue;  // the front end saw only zero bytes: k_tree turns this block into Fill(0) without reading it
+        if ((uint32_t)__popc(segmask) <= kSmallSegments) continue;  // all zero (k_tree: Fill(0)) or small (k_tree takes the histogram itself)
         const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
         const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
         if (tid < kSymStride) s_hist[tid] = 0;
@@ -236,7 +249,80 @@ struct TreeLds {
     uint16_t sbits[2 * kNumSym];  // description bits of the subtree
     uint16_t leafsym[kSymStride];
     uint32_t tdesc[kTdescWords];
+    uint32_t lhist[kSymStride];  // token histogram of this wave's block
 };
+
+// add the tokens of a zero run of length R to a histogram (same split as run_bits / run_emit)
+__device__ __forceinline__ void run_count(uint32_t* h, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    if (q) atomicAdd(&h[260], q);
+    if (rem) atomicAdd(&h[run_symbol(rem)], 1u);
+}
+
+// token histogram of a small block by one wave (zero runs are counted where they END; see encode_small_block)
+__device__ __forceinline__ void small_block_hist(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t* h) {
+    const uint32_t l = lane_id();
+    const unsigned long long lt = (1ull << l) - 1ull;
+    const uint32_t nseg = (in_size + 4095u) >> 12;
+    uint32_t pend = 0;
+    for (uint32_t seg = 0; seg < nseg; ++seg) {
+        const uint32_t seg_base = seg << 12;
+        if (!((segmask >> seg) & 1u)) {
+            pend += min(4096u, in_size - seg_base);
+            continue;
+        }
+        uint4 rows[4];
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {  // the segment's four rows in one round trip
+            const uint32_t pos = seg_base + (r << 10) + 16u * l;
+            rows[r] = make_uint4(0, 0, 0, 0);
+            if (pos < in_size) rows[r] = *reinterpret_cast<const uint4*>(in + pos);
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 4; ++r) {
+            const uint32_t base = seg_base + (r << 10);
+            if (base < in_size) {
+                const uint32_t row_valid = min(1024u, in_size - base);
+                Granule gr;
+                const uint32_t pos = base + 16u * l;
+                gr.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
+                gr.w[0] = rows[r].x;
+                gr.w[1] = rows[r].y;
+                gr.w[2] = rows[r].z;
+                gr.w[3] = rows[r].w;
+                granule_finish(gr);
+                const uint32_t lits = ~gr.zm & ((1u << gr.nv) - 1u);
+                const unsigned long long nzb = __ballot(lits != 0);
+                if (!nzb) {
+                    pend += row_valid;
+                } else {
+                    const uint32_t last_nz = lits ? 31u - (uint32_t)__builtin_clz(lits) : 0u;
+                    const uint32_t trail = lits ? (15u - last_nz) : 16u;
+                    const unsigned long long below = nzb & lt;
+                    const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+                    const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
+                    const uint32_t zb = below ? (16u * (l - 1u - p) + tp) : (16u * l + pend);
+                    uint32_t t = lits, prev_end = 0;
+                    bool first = true;
+                    while (t) {
+                        const uint32_t i = (uint32_t)__builtin_ctz(t);
+                        t &= t - 1;
+                        const uint32_t R = first ? (zb + i) : (i - prev_end);
+                        if (R) run_count(h, R);
+                        atomicAdd(&h[granule_byte_dyn(gr.w[0], gr.w[1], gr.w[2], gr.w[3], i)], 1u);
+                        prev_end = i + 1;
+                        first = false;
+                    }
+                    const uint32_t pl = 63u - (uint32_t)__builtin_clzll(nzb);
+                    const uint32_t lastlit = (uint32_t)__shfl((int)last_nz, (int)pl, 64);
+                    pend = row_valid - (16u * pl + lastlit + 1u);
+                }
+            }
+        }
+    }
+    if (pend && l == 0) run_count(h, pend);
+}
 
 // The merge loop with the live keys in NREG registers per lane (node i lives
 // in lane i&63, register i>>6).  Each iteration extracts the two smallest keys
@@ -276,9 +362,10 @@ __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
     }
 }
 
-__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, Geom g, const uint32_t* __restrict__ nbuse,
-                                                         const uint32_t* __restrict__ nzflag, uint32_t nhb_total, uint32_t* __restrict__ cw,
-                                                         uint32_t* __restrict__ tdesc, BlockMeta* __restrict__ meta) {
+__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, const uint8_t* __restrict__ planes, Geom g,
+                                                         const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
+                                                         uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
+                                                         BlockMeta* __restrict__ meta) {
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
@@ -290,12 +377,23 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
         return;
     }
-    if (!nzflag[hb]) {  // all-zero block (flagged by the front end): EncodeFill with value 0
+    const uint32_t segmask = nzflag[hb];
+    if (!segmask) {  // all-zero block (flagged by the front end): EncodeFill with value 0
         if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
         return;
     }
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    const uint32_t* h = hist + (size_t)hb * kSymStride;
+    uint32_t* h = t.lhist;
+    if ((uint32_t)__popc(segmask) <= kSmallSegments) {  // small block: this wave takes the histogram itself
+        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        small_block_hist(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock, in_size, segmask, h);
+    } else {
+        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = hist[(size_t)hb * kSymStride + i];
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
 
     // ---- leaves in ascending symbol order (hzr_encode.c:226-234) ----------
     uint32_t cnt[5], idx[5];
@@ -405,9 +503,6 @@ __device__ __forceinline__ void store_le32(uint8_t* p, uint32_t v) {
 // It also sorts the hzr blocks into the work queues of k_encode: Fill blocks (8 bytes) are written
 // right here; Huffman blocks with few tokens and a small payload go to the `small` queue (one WAVE encodes one such
 // block), everything else to the `big` queue (one 1024-thread workgroup per block).
-constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
-constexpr uint32_t kSmallTokens = 512;    // a single wave walks the block row by row: only worth it for few tokens ...
-constexpr uint32_t kSmallSegments = 2;    // ... in few non-zero 4 KiB segments (each costs one dependent HBM round trip)
 
 struct WorkQueues {
     uint32_t n_big, n_small;      // filled by k_layout
@@ -542,12 +637,6 @@ struct BitSink {
         if (n) atomicOr(&stage[skew(word)], lo);
     }
 };
-
-// byte i (dynamic) of a granule held in four registers
-__device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
-    const uint32_t lo = (i & 8u) ? w2 : w0, hi = (i & 8u) ? w3 : w1;
-    return __builtin_amdgcn_perm(hi, lo, 0x0C0C0C00u | (i & 7u));  // byte (i & 7) of {hi,lo}, zero-extended
-}
 
 // pass 1: number of stream bits of the tokens that start in this granule
 __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,

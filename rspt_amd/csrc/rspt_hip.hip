@@ -519,7 +519,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->work_ctr, nhb);
 
     stamp(p, ST_TREE, st);
-    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta);
+    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta);
 
     stamp(p, ST_LAYOUT, st);
     WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
