@@ -103,7 +103,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -139,7 +139,7 @@ def main():
     # that step i's gather overlaps step i+1's compression.
     from rspt_amd import shard
 
-    do_gather = world > 1 and not args.no_gather
+    do_gather = dist is not None and not args.no_gather
     side = torch.cuda.Stream(dev) if do_gather else None
     bound = pk.pack_bound(B)
     packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(2)] if do_gather else None

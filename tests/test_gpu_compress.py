@@ -136,3 +136,29 @@ def test_full_size_roundtrip_properties(api, orc):
     torch.cuda.synchronize()
     assert d1[0, : int(s1[0])].cpu().numpy().tobytes() == d_dst[1, : int(sizes[1])].cpu().numpy().tobytes()
     pk.close()
+
+
+def test_pack_batch_container(api, orc):
+    """rspt_hip_pack_batch_dev: the device-side container == the streams, in block order,
+    readable by the host-side parser the multi-GPU gather uses (rspt_amd/shard.py)."""
+    import torch
+
+    from rspt_amd import shard
+
+    nch, ns, bps = 4, 2500, 4
+    blocks = [cases._rand_native(nch, ns, bps, 600 + i, [40, 1 << 13, 90, 7][i % 4], walk=bool(i & 1)) for i in range(9)]
+    pk = api.new_xdelta_hzr(bps, nch, ns, 1)
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    d_packed, d_total = pk.pack_batch(d_dst, d_sizes)
+    torch.cuda.synchronize()
+    total = int(d_total.item())
+    assert total <= pk.pack_bound(len(blocks))
+    streams, nb = shard.unpack_container(d_packed[:total].cpu().numpy().tobytes())
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 1)
+    want = [po.compress(b) for b in blocks]
+    assert streams == want
+    assert nb == orc.packer_nb(po) == pk.nb
+    # host-side packer produces the same bytes
+    assert shard.pack_container(want, nb) == d_packed[:total].cpu().numpy().tobytes()
+    pk.close()
