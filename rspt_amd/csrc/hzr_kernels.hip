@@ -23,6 +23,16 @@ namespace rspt {
 // of 1 KiB; lane l of row r owns the granule at 4096w + 1024r + 16l, so every
 // global load is a fully coalesced 1 KiB wave access.
 // ===========================================================================
+// threadIdx.x behind an empty asm: inside the persistent loops this keeps everything derived
+// from the thread id (lane masks, offsets) loop-VARIANT, so hipcc recomputes it per block instead
+// of hoisting it out of the loop and holding it in VGPRs across the register-tight emit pass
+// (k_hist: 20 -> 0 bytes of scratch, k_encode: 188 -> ~100).
+__device__ __forceinline__ uint32_t thread_id() {
+    uint32_t t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 struct LaneBlock {
     Granule g[4];
     uint32_t zb[4];  // zeros immediately before granule r (cut at the block start)
@@ -32,7 +42,7 @@ struct LaneBlock {
 // scratch: 2*kEncWaves uint32.  segmask bit w = "the 4 KiB segment of wave w holds a non-zero byte"
 // (front-end non-zero map): a wave whose bit is clear does not read HBM at all.
 __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, LaneBlock& L, uint32_t* scratch) {
-    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
     const bool seg_nz = (segmask >> w) & 1u;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -137,7 +147,7 @@ constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + 
 // starts: at the block start (no zeros before) or at a multiple of 16662 inside the
 // run (hzr_encode.c:149).  Wave-uniform, so whole waves skip their token loops.
 __device__ __forceinline__ bool wave_may_have_tokens(uint32_t segmask, const LaneBlock& L) {
-    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t w = thread_id() >> 6;
     if ((segmask >> w) & 1u) return true;
     const uint32_t zb0 = (uint32_t)__shfl((int)L.zb[0], 0, 64);  // zeros before the wave's first byte
     const uint32_t q = (zb0 >= kRunCap) + (zb0 >= 2 * kRunCap) + (zb0 >= 3 * kRunCap);
@@ -768,7 +778,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
     if ((ablate & 4096u) && m.payload_len < 256u) return;   // timing probe: small blocks cost nothing
     if ((ablate & 8192u) && m.payload_len >= 256u) return;  // timing probe: large blocks cost nothing
     if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
-    const uint32_t tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
     uint8_t* o = dst + (size_t)b * dst_stride + off;
 
     if (ablate & 64u) {  // occupancy census: every non-fill workgroup idles ~100 us (s_memrealtime ticks at 100 MHz)
