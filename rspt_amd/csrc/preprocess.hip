@@ -19,6 +19,10 @@
 
 namespace rspt {
 
+// q / d for q < 2^32 / d by one multiply: M = ceil(2^32 / d)  (d >= 2; d == 1 handled by the caller)
+__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
+__device__ __forceinline__ uint32_t fast_div(uint32_t q, uint32_t d, uint32_t M) { return d == 1 ? q : __umulhi(q, M); }
+
 template <int BPS>
 __device__ __forceinline__ int32_t sample_from_bytes(const uint8_t* p, bool aligned) {
     if (BPS == 4) {
@@ -59,15 +63,20 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
 // call (signal_packer_xdelta_hzr.cpp:63-69), a second launch with nbuse != nullptr adds the
 // missing planes for exactly the blocks that need them and exits at once for all others.
 template <int BPS, bool XDELTA>
-__global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
+__global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                      uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
-                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse) {
+                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
+                                                     uint32_t nblocks) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t b = blockIdx.y;
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const bool fixup = nbuse != nullptr;
-    if (fixup && nbuse[b] <= kfirst) return;
-    const uint32_t s0 = blockIdx.x * T;
+    const uint32_t tiles_per_block = (g.ns + T - 1) / T;
+    // persistent: the grid is a few workgroups per CU, each walks tiles with a fixed stride
+    for (uint32_t work = blockIdx.x; work < tiles_per_block * nblocks; work += gridDim.x) {
+    const uint32_t b = work / tiles_per_block;
+    if (fixup && nbuse[b] <= kfirst) continue;
+    const uint32_t s0 = (work - b * tiles_per_block) * T;
+    __syncthreads();  // the previous tile's rows have left LDS
     const uint32_t Tn = min(T, g.ns - s0);
     const uint8_t* blk = src + (size_t)b * g.block_bytes;
     const bool aligned4 = (BPS == 4) && ((reinterpret_cast<uintptr_t>(blk) & 3u) == 0);
@@ -78,15 +87,16 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
     // The first setter of a bit in the workgroup forwards it to HBM.  A tile row (<= 2048
     // samples) touches at most two hzr blocks: dedupe masks are kept as [rel][plane][channel].
     uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)kcount * g.nch * RS);
-    for (uint32_t i = tid; i < 8 * g.nch; i += 256) s_nz[i] = 0;
+    for (uint32_t i = tid; i < 8 * g.nch; i += nthr) s_nz[i] = 0;
     __syncthreads();
 
     // ---- per (channel, 16-sample group): load, transform, plane split ---------
     const uint32_t ngrp = (Tn + 15) >> 4;
     const uint32_t nitems = g.nch * ngrp;
+    const uint32_t m_nch = magic_of(g.nch);
     uint32_t mag = 0;
-    for (uint32_t q = tid; q < nitems; q += 256) {
-        const uint32_t grp = q / g.nch;
+    for (uint32_t q = tid; q < nitems; q += nthr) {
+        const uint32_t grp = fast_div(q, g.nch, m_nch);
         const uint32_t c = q - grp * g.nch;
         const uint32_t t0 = grp << 4;
         const uint32_t cnt = min(16u, Tn - t0);
@@ -94,7 +104,7 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
         const size_t rstride = (size_t)g.nch * BPS;
         uint32_t pv[16];
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+        for (uint32_t e = 0; e < 16; ++e) pv[e] = (e < cnt && !(ablate & 32768u)) ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
         uint32_t p1 = 0, oprev = 0;  // p[i-1], o[i-1]
         if (XDELTA) {
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
@@ -138,39 +148,46 @@ __global__ __launch_bounds__(256) void k_tile_planes(const uint8_t* __restrict__
         for (uint32_t k = 0; k < 4; ++k) {
             uint4 w = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
             if (k >= kfirst && k < kfirst + kcount) *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = w;
-            if (!fixup && (w.x | w.y | w.z | w.w)) {  // (an item straddling a segment edge marks both sides: conservative)
+            if (!fixup && !(ablate & 65536u) && (w.x | w.y | w.z | w.w)) {  // (an item straddling a segment edge marks both sides: conservative)
                 const uint32_t ja = f0 >> 16, jz = f1 >> 16;
                 const uint32_t ba = 1u << ((f0 >> 12) & 15u), bz = 1u << ((f1 >> 12) & 15u);
+                // (fire-and-forget: a read-before-atomic here would put a dependent HBM round trip into the item loop)
                 if (!(atomicOr(&s_nz[((ja - jb) * 4 + k) * g.nch + c], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
                 if ((jz != ja || bz != ba) && !(atomicOr(&s_nz[((jz - jb) * 4 + k) * g.nch + c], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
             }
         }
     }
     if (XDELTA && !fixup) {
+        // only the three thresholds matter (need_from_mask): fold to the top bit of each byte range, and
+        // skip the same-address atomic when the block's mask already has it (750 tiles x waves per block)
         mag = wave_or_u32(mag);
-        if (lane_id() == 0 && mag) atomicOr(&needmask[b], mag);
+        const uint32_t f = (mag >= 0x80u ? 0x80u : 0u) | (mag >= 0x8000u ? 0x8000u : 0u) | (mag >= 0x800000u ? 0x800000u : 0u);
+        if (lane_id() == 0 && f && !(ablate & 131072u) && (__builtin_nontemporal_load(&needmask[b]) & f) != f) atomicOr(&needmask[b], f);
     }
     __syncthreads();
 
     // ---- plane rows -> HBM ------------------------------------------------------
     const uint32_t upr = ngrp;  // 16-byte units per row
     const uint32_t nunits = kcount * g.nch * upr;
+    const uint32_t m_upr = magic_of(upr);
     const bool fast = ((g.ns & 15) == 0) && ((s0 & 15) == 0);
-    for (uint32_t u = tid; u < nunits; u += 256) {
-        const uint32_t row = u / upr;  // (k-kfirst)*nch + c
+    for (uint32_t u = tid; u < nunits; u += nthr) {
+        const uint32_t row = fast_div(u, upr, m_upr);  // (k-kfirst)*nch + c
         const uint32_t colu = u - row * upr;
-        const uint32_t kr = row / g.nch;
+        const uint32_t kr = fast_div(row, g.nch, m_nch);
         const uint32_t c = row - kr * g.nch;
         const uint32_t k = kfirst + kr;
         const uint32_t nbytes = min(16u, Tn - colu * 16);
         const uint8_t* sp = out + (size_t)row * RS + colu * 16;
         uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + colu * 16;
+        if (ablate & 16384u) continue;  // timing probe: no stores
         if (fast && nbytes == 16) {
             *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
         } else {
             for (uint32_t i = 0; i < nbytes; ++i) dp[i] = sp[i];
         }
     }
+    }  // tile loop
 }
 
 // planar int32 [nch][ns] (the output of a transform kernel) -> planes, with the
@@ -292,8 +309,8 @@ __global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ n
 
 // explicit instantiations used by rspt_hip.cpp
 #define INST_TILE(BPS)                                                                                                   \
-    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*);    \
-    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*);   \
+    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t);    \
+    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t);   \
     template __global__ void k_tile_planar<BPS>(const uint8_t*, Geom, uint32_t, int32_t*);
 INST_TILE(1)
 INST_TILE(2)

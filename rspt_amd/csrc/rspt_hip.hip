@@ -143,6 +143,7 @@ struct rspt_hip_packer {
     uint32_t Tp[5] = {0, 0, 0, 0, 0};  // k_tile_planes: tile length when kcount planes are staged: rows [kcount*nch][Tp+16] + nz flags
 
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
+    uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
 
     // profiling
@@ -170,9 +171,13 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     const Geom& g = p->g;
     const uint32_t T = p->Tp[kcount];
     const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch;
-    dim3 grid((g.ns + T - 1) / T, (unsigned)nblocks);
+    const uint32_t ntiles = (uint32_t)((g.ns + T - 1) / T * nblocks);
+    const uint32_t per_cu = lds <= 40 * 1024 ? 4u : lds <= 80 * 1024 ? 2u : 1u;
+    uint32_t want = per_cu * (uint32_t)p->num_cu;
+    if (const char* e = getenv("RSPT_K1_GRID")) want = (uint32_t)atoi(e);
+    dim3 grid(want < ntiles ? want : ntiles);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse);
+    hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(p->k1_threads), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate, (uint32_t)nblocks);
 }
 
 // main front-end pass; returns the number of planes it wrote (xdelta: nb as last seen by the host)
@@ -322,6 +327,8 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         }
     }
     if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
+    if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
+    if (p->k1_threads < 64 || p->k1_threads > 1024) p->k1_threads = 256;
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
     {
         // k_planar_native tile: nch rows of (T+1) int32 within 64 KiB
