@@ -103,8 +103,13 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
         const size_t rstride = (size_t)g.nch * BPS;
         uint32_t pv[16];
+        if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) pv[e] = (e < cnt && !(ablate & 32768u)) ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+            for (uint32_t e = 0; e < 16; ++e) pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < 16; ++e) pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+        }
         uint32_t p1 = 0, oprev = 0;  // p[i-1], o[i-1]
         if (XDELTA) {
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
@@ -119,28 +124,29 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
             oprev = (flat == 0) ? 0u : (p1 - p2 - 128u);  // xor_encode_32 starts from last = 0
         }
         uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+        // elements past cnt (last group of a ragged tile only) are computed on zeros and never stored or flagged:
+        // their plane bytes are masked off below
 #pragma unroll
         for (uint32_t e = 0; e < 16; ++e) {
-            if (e < cnt) {
-                const uint32_t p = pv[e];
-                uint32_t v;
-                if (XDELTA) {
-                    const uint32_t o = p - p1 - 128u;
-                    v = o ^ oprev;
-                    oprev = o;
-                    p1 = p;
-                    // sign-extend from the sample width, fold to a magnitude (escalation test)
-                    const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
-                    mag |= (uint32_t)(x ^ (x >> 31));
-                } else {
-                    v = p;
-                }
-                const uint32_t sh = (e & 3) * 8;
-                pw[0][e >> 2] |= (v & 0xFFu) << sh;
-                pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
-                pw[2][e >> 2] |= ((v >> 16) & 0xFFu) << sh;
-                pw[3][e >> 2] |= (v >> 24) << sh;
+            const uint32_t p = pv[e];
+            uint32_t v;
+            if (XDELTA) {
+                const uint32_t o = p - p1 - 128u;
+                v = o ^ oprev;
+                oprev = o;
+                p1 = p;
+                // sign-extend from the sample width, fold to a magnitude (escalation test)
+                const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
+                mag |= e < cnt ? (uint32_t)(x ^ (x >> 31)) : 0u;
+            } else {
+                v = p;
             }
+            v = e < cnt ? v : 0u;
+            const uint32_t sh = (e & 3) * 8;
+            pw[0][e >> 2] |= (v & 0xFFu) << sh;
+            pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
+            pw[2][e >> 2] |= ((v >> 16) & 0xFFu) << sh;
+            pw[3][e >> 2] |= (v >> 24) << sh;
         }
         const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
         const uint32_t jb = (c * g.ns + s0) >> 16;
