@@ -151,6 +151,68 @@ class Oracle(_Lib):
         L.orc_fwht.restype, L.orc_fwht.argtypes = None, [C.POINTER(C.c_int32), C.c_size_t]
         L.orc_average_32.restype, L.orc_average_32.argtypes = C.c_int32, [C.POINTER(C.c_int32), C.c_size_t]
 
+    # ---- dct beyond the dense table (ns > 8192): fp64 restatement -----------------------------
+    # Same definition as signal_packer_dct.cpp:76-100 with the cosines in fp64 instead of the float32
+    # table (which cannot be built at this size); the sum is evaluated by scipy's fp64 DCT.
+    # PARITY NOTE: no reference run exists for these sizes; at ns <= 8192 the same routine is checked
+    # against the real reference under SURVEY 8(d)'s PRDN / CR gate (tests/test_oracle_golden.py).
+    def dct_big_compress(self, native, bps, nch, ns):
+        import scipy.fft
+
+        L = self.lib
+        L.orc_packer_compress_coeffs.restype = C.c_int
+        L.orc_packer_compress_coeffs.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _u8p, C.c_size_t, _szp]
+        x = self.native_to_i32(native, ns, nch, bps)
+        means = np.array([self.average_32(x[c]) for c in range(nch)], dtype=np.int32)
+        s = (x - means[:, None]).astype(np.int32).astype(np.float32).astype(np.float64)  # (float)src: dct.cpp:80
+        csum = scipy.fft.dct(s, type=2, axis=1) * 0.5  # sum_x s[x] cos(pi (2x+1) i / 2n)
+        ratio1 = np.sqrt(2.0 / ns)
+        cs0 = np.float32(1 / np.sqrt(2))
+        scale = np.full(ns, float(np.float32(1.0)) * ratio1 / 128.0)
+        scale[0] = float(cs0) * ratio1 / 128.0
+        coeffs = np.ascontiguousarray(np.trunc(csum * scale[None, :]).astype(np.int64).astype(np.int32))
+        pk = self.packer("dct", bps, nch, ns)
+        cap = self.packer_max_compressed_size(pk) + 64
+        out = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = L.orc_packer_compress_coeffs(pk._h, coeffs.ctypes.data_as(C.POINTER(C.c_int32)), means.ctypes.data_as(C.POINTER(C.c_int32)),
+                                          _ptr(out), cap, C.byref(n))
+        pk.close()
+        if rc:
+            raise RuntimeError("compress_coeffs rc=%d" % rc)
+        return out[: n.value].tobytes(), coeffs
+
+    def dct_big_decompress(self, stream, bps, nch, ns):
+        import scipy.fft
+
+        L = self.lib
+        L.orc_packer_decompress_coeffs.restype = C.c_int
+        L.orc_packer_decompress_coeffs.argtypes = [C.c_void_p, _u8p, _szp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.orc_i32_to_native.restype = None
+        L.orc_i32_to_native.argtypes = [_u8p, C.POINTER(C.c_int32), C.c_size_t, C.c_size_t, C.c_size_t]
+        s = _as_u8(stream)
+        padded = np.zeros(s.size + 16, dtype=np.uint8)
+        padded[: s.size] = s
+        coeffs = np.zeros((nch, ns), dtype=np.int32)
+        means = np.zeros(nch, dtype=np.int32)
+        used = C.c_size_t(0)
+        pk = self.packer("dct", bps, nch, ns)
+        rc = L.orc_packer_decompress_coeffs(pk._h, _ptr(padded), C.byref(used), coeffs.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            means.ctypes.data_as(C.POINTER(C.c_int32)))
+        pk.close()
+        if rc:
+            raise RuntimeError("decompress_coeffs rc=%d" % rc)
+        y = coeffs.astype(np.float32).astype(np.float64)
+        y[:, 0] = (np.float32(1 / np.sqrt(2)) * coeffs[:, 0].astype(np.float32)).astype(np.float64)  # Cs[0]*dct[0] in float (dct.cpp:95)
+        # sum_x Y[x] cos(pi (2i+1) x / 2n) = DCT-III with full weight on Y[0]: scipy's type 3 is Y0 + 2 sum_{x>0}
+        y[:, 1:] *= 0.5
+        rec = scipy.fft.dct(y, type=3, axis=1)
+        rec = np.trunc(rec * (np.sqrt(2.0 / ns) * 128.0)).astype(np.int64).astype(np.int32)
+        rec = np.ascontiguousarray((rec.astype(np.int64) + means[:, None]).astype(np.int32))  # wrap like int32 add
+        out = np.zeros(bps * nch * ns + 8, dtype=np.uint8)
+        L.orc_i32_to_native(_ptr(out), rec.ctypes.data_as(C.POINTER(C.c_int32)), ns, nch, bps)
+        return out[: bps * nch * ns].tobytes(), used.value
+
     def crc32c(self, data):
         a = _as_u8(data)
         src = a if a.size else np.zeros(1, dtype=np.uint8)

@@ -655,15 +655,15 @@ orc_packer* orc_packer_new(int kind, size_t bps, size_t nch, size_t ns, size_t n
         free(p);
         return NULL;
     }
-    if (kind == ORC_KIND_DCT && ns > 8192) { /* n*n float table */
-        free(p);
-        return NULL;
-    }
+    /* dct with ns > 8192: the reference's n*n float table is out of reach.  The handle is
+     * still created, without the table: only the *_coeffs entry points work on it (framing around a
+     * transform the caller evaluates in fp64). */
+    const int dct_table = kind == ORC_KIND_DCT && ns <= 8192;
     p->enc = (int32_t*)calloc(p->n, sizeof(int32_t));
     p->tmp = (int32_t*)calloc(p->ns, sizeof(int32_t));
     p->planes = (uint8_t*)calloc(4 * p->n, 1);
     p->verify = (uint8_t*)calloc(p->n * bps, 1);
-    if (kind == ORC_KIND_DCT) {
+    if (dct_table) {
         /* signal_packer_dct.cpp:60-74: COS[x][i] = (float)cos(((2x+1)*i) * PI/(2n)) */
         const double PI = 3.14159265358979323846;
         double step = PI / ((double)ns * 2.0);
@@ -675,7 +675,7 @@ orc_packer* orc_packer_new(int kind, size_t bps, size_t nch, size_t ns, size_t n
                     p->cos_tab[x * ns + i] = (float)cos(arg * step);
                 }
     }
-    if (!p->enc || !p->tmp || !p->planes || !p->verify || (kind == ORC_KIND_DCT && !p->cos_tab)) {
+    if (!p->enc || !p->tmp || !p->planes || !p->verify || (dct_table && !p->cos_tab)) {
         orc_packer_free(p);
         return NULL;
     }
@@ -825,7 +825,38 @@ static void dct_inverse(const orc_packer* p, const int32_t* src, int32_t* dst) {
     }
 }
 
+/* Framing of the lossy packers around externally evaluated transform coefficients: what
+ * signal_packer_dct.cpp:117-127 / signal_packer_hadamard.cpp:73-80 do after the transform.
+ * coeffs = [nch][ns] transform output (dct: before the flat delta/xor), means = [nch]. */
+int orc_packer_compress_coeffs(orc_packer* p, const int32_t* coeffs, const int32_t* means, uint8_t* dst, size_t dst_max_len,
+                               size_t* dst_len) {
+    if (p->kind != ORC_KIND_DCT && p->kind != ORC_KIND_HADAMARD) return -3;
+    size_t hlen = header_len(p);
+    uint8_t* header = (uint8_t*)malloc(hlen);
+    memcpy(p->enc, coeffs, sizeof(int32_t) * p->n);
+    if (p->kind == ORC_KIND_DCT) orc_xdelta_forward(p->enc, p->n); /* dct.cpp:117-119 */
+    means_header(means, p->nch, header);
+    int rc = compress_i32(p, dst, dst_max_len, dst_len, p->kind == ORC_KIND_DCT ? 1 : 2, p->nb, header, hlen);
+    free(header);
+    return rc;
+}
+
+/* Inverse of the above: dct.cpp:130-139 / hadamard.cpp:83-92 up to (not including) the inverse transform. */
+int orc_packer_decompress_coeffs(orc_packer* p, const uint8_t* src, size_t* src_len, int32_t* coeffs, int32_t* means) {
+    if (p->kind != ORC_KIND_DCT && p->kind != ORC_KIND_HADAMARD) return -3;
+    uint8_t method = 0;
+    size_t hlen = header_len(p);
+    uint8_t* header = (uint8_t*)malloc(hlen);
+    decompress_i32(p, src, src_len, &method, p->nb, header, hlen);
+    if (p->kind == ORC_KIND_DCT) orc_xdelta_inverse(p->enc, p->n);
+    memcpy(coeffs, p->enc, sizeof(int32_t) * p->n);
+    for (size_t c = 0; c < p->nch; ++c) means[c] = mean_from_header(header, c);
+    free(header);
+    return 0;
+}
+
 int orc_packer_decompress(orc_packer* p, const uint8_t* src, size_t* src_len, uint8_t* dst) {
+    if (p->kind == ORC_KIND_DCT && !p->cos_tab) return -3;
     uint8_t method = 0;
     size_t hlen = header_len(p);
     uint8_t* header = hlen ? (uint8_t*)malloc(hlen) : NULL;
@@ -855,6 +886,7 @@ int orc_packer_decompress(orc_packer* p, const uint8_t* src, size_t* src_len, ui
 }
 
 int orc_packer_compress(orc_packer* p, const uint8_t* src, uint8_t* dst, size_t dst_max_len, size_t* dst_len) {
+    if (p->kind == ORC_KIND_DCT && !p->cos_tab) return -3;
     size_t hlen = header_len(p);
     int rc = 0;
     switch (p->kind) {

@@ -88,6 +88,14 @@ int orc_packer_compress(orc_packer* p, const uint8_t* src, uint8_t* dst, size_t 
 /* i_signal_packer::decompress (signal_packer.h:57).  *src_len is an output. */
 int orc_packer_decompress(orc_packer* p, const uint8_t* src, size_t* src_len, uint8_t* dst);
 
+/* dct / hadamard framing around transform coefficients the caller evaluated itself
+ * (signal_packer_dct.cpp:117-127,130-139; signal_packer_hadamard.cpp:73-80,83-92).  Used for dct at
+ * ns > 8192, where the reference's n*n float table cannot be built and the transform is
+ * restated in fp64 (oracle.py: dct_big_*).  coeffs = [nch][ns], means = [nch]. */
+int orc_packer_compress_coeffs(orc_packer* p, const int32_t* coeffs, const int32_t* means, uint8_t* dst, size_t dst_max_len,
+                               size_t* dst_len);
+int orc_packer_decompress_coeffs(orc_packer* p, const uint8_t* src, size_t* src_len, int32_t* coeffs, int32_t* means);
+
 /* current nr_bytes_to_compress_ (mutates on escalation, xdelta_hzr.cpp:66). */
 unsigned orc_packer_nb(const orc_packer* p);
 /* 0: escalate by round-trip + memcmp like the reference (default);

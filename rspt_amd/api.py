@@ -48,6 +48,11 @@ def lib():
         path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("rspt_amd: %s is missing and cannot be built here; there is no CPU fallback" % path)
+    # One HIP runtime per process: torch ships its own libamdhip64 and the batch entry points take torch
+    # tensors, so torch's copy has to be the one the loader binds first (a process that initialised
+    # /opt/rocm's runtime before importing torch leaves torch without a visible device).
+    import torch  # noqa: F401
+
     L = C.CDLL(path)
     L.rspt_hip_status_string.restype, L.rspt_hip_status_string.argtypes = C.c_char_p, [C.c_int]
     L.rspt_hip_last_hip_error.restype, L.rspt_hip_last_hip_error.argtypes = C.c_int, [C.c_void_p]

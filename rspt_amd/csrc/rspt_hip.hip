@@ -129,6 +129,14 @@ struct rspt_hip_packer {
     float* cos_tab_t = nullptr;
     double dct_scale0 = 0, dct_scale1 = 0, idct_scale = 0;
     float dct_cs0 = 0;
+    // dct beyond the dense table: fp64 FFT path (transforms.hip: k_dctfft_*)
+    bool dct_fft = false;
+    uint32_t fft_l1 = 0, fft_l2 = 0;   // n = 2^(l1+l2)
+    double2* fft_tw = nullptr;         // [n] (cos, sin)(2 pi t / n)
+    double2* fft_post = nullptr;       // [n] (cos, sin)(pi k / 2n)
+    double2* fft_scratch = nullptr;    // [fft_bpp][nch][n]
+    size_t fft_bpp = 0;                // blocks per pass (bounds the scratch to ~1 GiB)
+    int32_t* mean_i32 = nullptr;       // [cap][nch]
     uint32_t ntile = 0;
     uint32_t Tn_native = 0;  // tile of k_planar_native
 
@@ -200,6 +208,24 @@ static uint32_t launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nb
 }
 
 // escalation fix-up: planes [np, 4) for the blocks whose nb grew past np in this call
+// dct / idct of every channel of B blocks through the fp64 FFT path, `fft_bpp` blocks per pass (scratch bound)
+template <bool FORWARD>
+static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, int32_t* out, hipStream_t st) {
+    const Geom& g = p->g;
+    const uint32_t l1 = p->fft_l1, l2 = p->fft_l2;
+    const uint32_t lw = std::min(kFftLdsLog - l1, l2), lr = std::min(kFftLdsLog - l2, l1);
+    const uint32_t lds_c = (uint32_t)sizeof(double2) << (l1 + lw), lds_r = (uint32_t)sizeof(double2) << (l2 + lr);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_cols<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_rows<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+    for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
+        const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
+        hipLaunchKernelGGL((k_dctfft_cols<FORWARD>), dim3(1u << (l2 - lw), g.nch, nbk), dim3(256), lds_c, st, in, g, p->mean_i32, p->fft_tw,
+                           p->fft_post, p->fft_scratch, l1, l2, b0, p->dct_cs0);
+        hipLaunchKernelGGL((k_dctfft_rows<FORWARD>), dim3(1u << (l1 - lr), g.nch, nbk), dim3(256), lds_r, st, p->fft_scratch, g, p->means,
+                           p->fft_tw, p->fft_post, out, l1, l2, b0, FORWARD ? p->dct_scale0 : 0.0, FORWARD ? p->dct_scale1 : p->idct_scale);
+    }
+}
+
 template <int BPS>
 static void launch_fixup(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, uint32_t np, hipStream_t st) {
     launch_planes<BPS, true>(p, d_src, nblocks, np, 4 - np, p->nbuse, st);
@@ -248,6 +274,10 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->txor);
     hipFree(p->tsum);
     hipFree(p->blk_off);
+    hipFree(p->fft_scratch);
+    hipFree(p->mean_i32);
+    p->fft_scratch = nullptr;
+    p->mean_i32 = nullptr;
     p->planar2 = nullptr;
     p->txor = p->tsum = nullptr;
     p->blk_off = nullptr;
@@ -345,9 +375,22 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         delete p;
         return RSPT_HIP_ERR_UNSUPPORTED;
     }
-    if (kind == RSPT_HIP_KIND_DCT && ns > 8192) {  // dense n x n table, as in the reference; FFT path: DESIGN.md
-        delete p;
-        return RSPT_HIP_ERR_UNSUPPORTED;
+    if (kind == RSPT_HIP_KIND_DCT) {
+        // n <= 8192: the reference's dense n x n table (bit-exact).  Larger n (where the reference cannot run):
+        // fp64 FFT path, n = 2^k only.  RSPT_DCT_FFT=1 forces the FFT path for small n (cross-check against the table path).
+        const char* force = getenv("RSPT_DCT_FFT");
+        const bool pow2 = (ns & (ns - 1)) == 0;
+        p->dct_fft = ns > 8192 || (force && atoi(force) != 0 && pow2 && ns >= 16);
+        if (p->dct_fft && (!pow2 || ns > (1u << 22))) {
+            delete p;
+            return RSPT_HIP_ERR_UNSUPPORTED;
+        }
+        if (p->dct_fft) {
+            uint32_t k = 0;
+            while ((1ull << k) < ns) ++k;
+            p->fft_l1 = (k + 1) / 2;
+            p->fft_l2 = k / 2;
+        }
     }
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -371,6 +414,32 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     }
     for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&p->ev[i]);
     if (kind == RSPT_HIP_KIND_DCT) {
+        const double ratio1 = sqrt(2.0 / (double)(int)ns);
+        const float cs0 = (float)(1 / sqrt(2));
+        p->dct_cs0 = cs0;
+        p->dct_scale0 = cs0 * ratio1 / 128.0;   // Cs[0]*ratio1/quality (dct.cpp:84)
+        p->dct_scale1 = 1.0f * ratio1 / 128.0;  // Cs[i>0] = 1
+        p->idct_scale = ratio1 * 128.0;          // dct.cpp:97
+    }
+    if (kind == RSPT_HIP_KIND_DCT && p->dct_fft) {
+        const size_t n = ns;
+        std::vector<double2> tw(n), post(n);
+        const double PI = 3.14159265358979323846;
+        for (size_t t = 0; t < n; ++t) {
+            const double a = 2.0 * PI * (double)t / (double)n, b = PI * (double)t / (2.0 * (double)n);
+            tw[t] = make_double2(cos(a), sin(a));
+            post[t] = make_double2(cos(b), sin(b));
+        }
+        if (hipMalloc(&p->fft_tw, n * sizeof(double2)) != hipSuccess || hipMalloc(&p->fft_post, n * sizeof(double2)) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_ALLOC;
+        }
+        if (hipMemcpy(p->fft_tw, tw.data(), n * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->fft_post, post.data(), n * sizeof(double2), hipMemcpyHostToDevice) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_LAUNCH;
+        }
+    } else if (kind == RSPT_HIP_KIND_DCT) {
         // init_cos_table (signal_packer_dct.cpp:60-74), host libm, same expression and types
         const size_t n = ns;
         std::vector<float> tab(n * n), tabt(n * n);
@@ -383,12 +452,6 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
                 tab[x * n + i] = v;
                 tabt[i * n + x] = v;
             }
-        const double ratio1 = sqrt(2.0 / (double)(int)n);
-        const float cs0 = (float)(1 / sqrt(2));
-        p->dct_cs0 = cs0;
-        p->dct_scale0 = cs0 * ratio1 / 128.0;   // Cs[0]*ratio1/quality (dct.cpp:84)
-        p->dct_scale1 = 1.0f * ratio1 / 128.0;  // Cs[i>0] = 1
-        p->idct_scale = ratio1 * 128.0;          // dct.cpp:97
         if (hipMalloc(&p->cos_tab, n * n * sizeof(float)) != hipSuccess || hipMalloc(&p->cos_tab_t, n * n * sizeof(float)) != hipSuccess) {
             rspt_hip_packer_destroy(p);
             return RSPT_HIP_ERR_ALLOC;
@@ -418,6 +481,8 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->nb_state);
     hipFree(p->cos_tab);
     hipFree(p->cos_tab_t);
+    hipFree(p->fft_tw);
+    hipFree(p->fft_post);
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
@@ -464,6 +529,12 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->tsum, max_blocks * (size_t)p->ntile * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->blk_off, nhb * sizeof(uint64_t)) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->planar2, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
+    if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {
+        const size_t per_block = (size_t)g.N * sizeof(double2);
+        p->fft_bpp = std::max<size_t>(1, std::min<size_t>(max_blocks, ((size_t)1 << 30) / per_block));
+        ok &= hipMalloc(&p->fft_scratch, p->fft_bpp * per_block) == hipSuccess;
+        ok &= hipMalloc(&p->mean_i32, max_blocks * (size_t)g.nch * sizeof(int32_t)) == hipSuccess;
+    }
     if (!ok) {
         free_workspace(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -503,8 +574,13 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         hipLaunchKernelGGL((k_fwht<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
         hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
-        hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
-                           p->cos_tab, p->dct_scale0, p->dct_scale1, p->dct_cs0, p->planar2);
+        if (p->dct_fft) {
+            hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
+            launch_dct_fft<true>(p, B, p->planar, p->planar2, st);
+        } else {
+            hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
+                               p->cos_tab, p->dct_scale0, p->dct_scale1, p->dct_cs0, p->planar2);
+        }
         hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes, p->nzflag);
     }
     HIPCHK(p, hipGetLastError());
@@ -675,8 +751,11 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
             hipLaunchKernelGGL((k_fwht<false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
         } else if (g.kind == RSPT_HIP_KIND_DCT) {
-            hipLaunchKernelGGL((k_dct<false>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
-                               p->cos_tab_t, 0.0, p->idct_scale, p->dct_cs0, p->planar2);
+            if (p->dct_fft)
+                launch_dct_fft<false>(p, B, p->planar, p->planar2, st);
+            else
+                hipLaunchKernelGGL((k_dct<false>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g,
+                                   p->means, p->cos_tab_t, 0.0, p->idct_scale, p->dct_cs0, p->planar2);
             final_planar = p->planar2;
         }
         const uint32_t T = min(p->Tn_native, g.ns);

@@ -200,6 +200,151 @@ __global__ __launch_bounds__(256) void k_dct(const int32_t* __restrict__ in, Geo
     }
 }
 
+// ---------------------------------------------------------------------------
+// DCT for n = 2^k beyond the dense table (n > 8192; BASELINE config 4 is n = 65536,
+// where the reference itself cannot run: 4n^2-byte table).  Same
+// definition as signal_packer_dct.cpp:76-100 -- X[i] = trunc(sum_x s[x]*cos(pi(2x+1)i/2n)
+// * Cs[i]*sqrt(2/n)/128) -- evaluated in fp64 through an n-point complex FFT
+// (Makhoul's even/odd permutation), so the parity gate is SURVEY 8(d)'s PRDN / CR
+// tolerance, not bit-exactness.
+//
+// Four-step FFT, n = n1*n2, input index j = j1*n2 + j2, output k = k1 + n1*k2:
+//   k_dctfft_cols  for W adjacent columns j2: length-n1 FFT over j1 in LDS, times
+//                  w_n^(j2*k1), to scratch[k1][j2]
+//   k_dctfft_rows  for R adjacent rows k1: length-n2 FFT over j2 in LDS, then the
+//                  DCT post-rotation (forward) or the inverse permutation.
+// tw[t] = (cos, sin)(2*pi*t/n), post[k] = (cos, sin)(pi*k/(2n)), both from host libm.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_row_means(const int32_t* __restrict__ planar, Geom g, uint8_t* __restrict__ means,
+                                                   int32_t* __restrict__ mean_i32) {
+    __shared__ long long s_red[16];
+    const uint32_t c = blockIdx.x, b = blockIdx.y;
+    const long long t = block_sum_row(planar + (size_t)b * g.N + (size_t)c * g.ns, g.ns, s_red);
+    if (threadIdx.x == 0) {
+        const int32_t m = mean_from_sum(t, g.ns);
+        store_mean_hdr(means, g, b, c, m);
+        mean_i32[(size_t)b * g.nch + c] = m;  // the subtraction uses all 32 bits, the header keeps 24 (dct.cpp:108-109,120-126)
+    }
+}
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return __brev(v) >> (32u - bits); }
+
+// radix-2 DIT over `len = 1<<logn` points of W = 1<<lw interleaved sequences: point p of sequence q at sh[p*W + q]
+__device__ __forceinline__ void lds_fft(double2* sh, uint32_t logn, uint32_t lw, const double2* __restrict__ tw, uint32_t nlog, bool inverse) {
+    const uint32_t W = 1u << lw;
+    const uint32_t nbf = (1u << (logn - 1)) << lw;
+    for (uint32_t s = 1; s <= logn; ++s) {
+        const uint32_t half = 1u << (s - 1);
+        for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
+            const uint32_t col = q & (W - 1), bf = q >> lw;
+            const uint32_t m = bf & (half - 1);
+            const uint32_t i0 = ((bf >> (s - 1)) << s) + m;
+            const double2 w = tw[(size_t)m << (nlog - s)];
+            const double ws = inverse ? w.y : -w.y;
+            const double2 a = sh[i0 * W + col], bq = sh[(i0 + half) * W + col];
+            const double tr = bq.x * w.x - bq.y * ws, ti = bq.x * ws + bq.y * w.x;
+            sh[i0 * W + col] = make_double2(a.x + tr, a.y + ti);
+            sh[(i0 + half) * W + col] = make_double2(a.x - tr, a.y - ti);
+        }
+        __syncthreads();
+    }
+}
+
+constexpr uint32_t kFftLdsLog = 12;  // 4096 complex fp64 points (64 KiB) per workgroup
+
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_dctfft_cols(const int32_t* __restrict__ in, Geom g, const int32_t* __restrict__ mean_i32,
+                                                    const double2* __restrict__ tw, const double2* __restrict__ post,
+                                                    double2* __restrict__ scratch, uint32_t l1, uint32_t l2, uint32_t b0, float cs0) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = l1 + l2;
+    const uint32_t lw = min(kFftLdsLog - l1, l2), W = 1u << lw;
+    const uint32_t j2_0 = blockIdx.x << lw, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const int32_t* row = in + (size_t)b * g.N + (size_t)c * n;
+    const uint32_t total = 1u << (l1 + lw);
+    const int32_t mean = FORWARD ? mean_i32[(size_t)b * g.nch + c] : 0;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), j1 = idx >> lw;
+        const uint32_t j = (j1 << l2) + j2_0 + col;
+        double2 v;
+        if (FORWARD) {
+            // v[j] = s[2j] (j < n/2), v[n-1-j] = s[2j+1]; s = (float)(src - mean) as in dct.cpp:80,108-109
+            const uint32_t x = j < (n >> 1) ? 2u * j : 2u * (n - 1u - j) + 1u;
+            const int32_t iv = (int32_t)((uint32_t)row[x] - (uint32_t)mean);
+            v = make_double2((double)(float)iv, 0.0);
+        } else {
+            // y = A^T Y  <=>  DCT-II(y) = (n, n/2, n/2, ...) * Y;  V[k]/n = e^{+i pi k/2n} (Y'[k] - i Y'[n-k])
+            double yk, ynk;
+            if (j == 0) {
+                yk = (double)__fmul_rn(cs0, (float)row[0]);  // Cs[0]*dct[0] in float (dct.cpp:95)
+                ynk = 0.0;
+            } else {
+                yk = 0.5 * (double)(float)row[j];
+                ynk = 0.5 * (double)(float)row[n - j];
+            }
+            const double2 pw = post[j];
+            v = make_double2(pw.x * yk + pw.y * ynk, pw.y * yk - pw.x * ynk);
+        }
+        shf[bitrev(j1, l1) * W + col] = v;
+    }
+    __syncthreads();
+    lds_fft(shf, l1, lw, tw, nlog, !FORWARD);
+    double2* dst = scratch + ((size_t)bl * g.nch + c) * n;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), k1 = idx >> lw;
+        const uint32_t j2 = j2_0 + col;
+        const double2 w = tw[j2 * k1];  // j2*k1 < n2*n1 = n
+        const double ws = FORWARD ? -w.y : w.y;
+        const double2 z = shf[k1 * W + col];
+        dst[((size_t)k1 << l2) + j2] = make_double2(z.x * w.x - z.y * ws, z.x * ws + z.y * w.x);
+    }
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_dctfft_rows(const double2* __restrict__ scratch, Geom g, const uint8_t* __restrict__ means,
+                                                    const double2* __restrict__ tw, const double2* __restrict__ post,
+                                                    int32_t* __restrict__ out, uint32_t l1, uint32_t l2, uint32_t b0, double scale0,
+                                                    double scale1) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = l1 + l2, n2 = 1u << l2;
+    const uint32_t lr = min(kFftLdsLog - l2, l1), R = 1u << lr;
+    const uint32_t k1_0 = blockIdx.x << lr, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const uint32_t total = 1u << (l2 + lr);
+    const double2* src = scratch + ((size_t)bl * g.nch + c) * n + ((size_t)k1_0 << l2);
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t r = idx >> l2, j2 = idx & (n2 - 1);
+        shf[bitrev(j2, l2) * R + r] = src[idx];
+    }
+    __syncthreads();
+    lds_fft(shf, l2, lr, tw, nlog, !FORWARD);
+    int32_t* orow = out + (size_t)b * g.N + (size_t)c * n;
+    const int32_t mean = FORWARD ? 0 : load_mean_hdr(means, g, b, c);
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t r = idx & (R - 1), k2 = idx >> lr;
+        const uint32_t k = k1_0 + r + (k2 << l1);
+        const double2 z = shf[k2 * R + r];
+        if (FORWARD) {
+            const double2 pw = post[k];
+            const double cval = pw.x * z.x + pw.y * z.y;            // Re(e^{-i pi k/2n} V[k])
+            const double sres = cval * (k == 0 ? scale0 : scale1);  // Cs[k]*sqrt(2/n)/128 (dct.cpp:84)
+            orow[k] = (int32_t)sres;                                  // C truncation (dct.cpp:85)
+        } else {
+            const uint32_t i = k < (n >> 1) ? 2u * k : 2u * (n - 1u - k) + 1u;
+            const double sres = z.x * scale1;  // sqrt(2/n)*128 (dct.cpp:97)
+            orow[i] = (int32_t)((uint32_t)(int32_t)sres + (uint32_t)mean);
+        }
+    }
+}
+
+template __global__ void k_dctfft_cols<true>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
+                                             uint32_t, float);
+template __global__ void k_dctfft_cols<false>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
+                                              uint32_t, float);
+template __global__ void k_dctfft_rows<true>(const double2*, Geom, const uint8_t*, const double2*, const double2*, int32_t*, uint32_t, uint32_t,
+                                             uint32_t, double, double);
+template __global__ void k_dctfft_rows<false>(const double2*, Geom, const uint8_t*, const double2*, const double2*, int32_t*, uint32_t, uint32_t,
+                                              uint32_t, double, double);
+
 template __global__ void k_fwht<true>(int32_t*, Geom, uint8_t*);
 template __global__ void k_fwht<false>(int32_t*, Geom, uint8_t*);
 template __global__ void k_dct<true>(const int32_t*, Geom, uint8_t*, const float*, double, double, float, int32_t*);
