@@ -71,42 +71,71 @@ __device__ __forceinline__ uint32_t hb_index(const Geom& g, uint32_t b, uint32_t
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
+// Cross-lane data movement goes through DPP (a VALU operand modifier, a few cycles) rather than
+// __shfl* (ds_bpermute_b32: an LDS-crossbar round trip per step).  Controls (GFX9 encoding):
+//   row_shr:n 0x110|n   row_shl:n 0x100|n   row_bcast:15 0x142   row_bcast:31 0x143
+// A row is 16 lanes, a bank 4 lanes.  Lanes whose source is outside the row, or that the masks
+// disable, keep `identity`.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp(uint32_t identity, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// inclusive scan over the 64 lanes; op(far, near): `far` aggregates lower lanes.  op must be associative
+// with identity `id`.
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v, uint32_t id, Op op) {
+    uint32_t r = op(dpp<0x111>(id, v), v);
+    r = op(dpp<0x112>(id, v), r);
+    r = op(dpp<0x113>(id, v), r);
+    r = op(dpp<0x114, 0xF, 0xE>(id, r), r);  // lanes 4..15 of each row: + [i-7, i-4]
+    r = op(dpp<0x118, 0xF, 0xC>(id, r), r);  // lanes 8..15: + [i-15, i-8]
+    r = op(dpp<0x142, 0xA, 0xF>(id, r), r);  // rows 1, 3: + total of the row before
+    r = op(dpp<0x143, 0xC, 0xF>(id, r), r);  // rows 2, 3: + total of rows 0..1
+    return r;
+}
+
+// scans over one row of 16 lanes (rows are independent): prefix (lower lanes = far) and suffix (higher lanes = far)
+template <class Op>
+__device__ __forceinline__ uint32_t row_scan_prefix(uint32_t v, uint32_t id, Op op) {
+    uint32_t r = op(dpp<0x111>(id, v), v);
+    r = op(dpp<0x112>(id, v), r);
+    r = op(dpp<0x113>(id, v), r);
+    r = op(dpp<0x114, 0xF, 0xE>(id, r), r);
+    r = op(dpp<0x118, 0xF, 0xC>(id, r), r);
+    return r;
+}
+template <class Op>
+__device__ __forceinline__ uint32_t row_scan_suffix(uint32_t v, uint32_t id, Op op) {
+    uint32_t r = op(dpp<0x101>(id, v), v);
+    r = op(dpp<0x102>(id, v), r);
+    r = op(dpp<0x103>(id, v), r);
+    r = op(dpp<0x104, 0xF, 0x7>(id, r), r);  // lanes 0..11: + [i+4, i+7]
+    r = op(dpp<0x108, 0xF, 0x3>(id, r), r);  // lanes 0..7:  + [i+8, i+15]
+    return r;
+}
+
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, uint32_t lane /* wave-uniform */) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
+// reductions: the result is wave-uniform (lives in an SGPR)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o < v ? o : v;
-    }
-    return v;  // identical in every lane
+    return read_lane(wave_scan_incl(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63);
 }
-
 __device__ __forceinline__ uint32_t wave_xor_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v ^= (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+    return read_lane(wave_scan_incl(v, 0u, [](uint32_t a, uint32_t b) { return a ^ b; }), 63);
 }
-
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+    return read_lane(wave_scan_incl(v, 0u, [](uint32_t a, uint32_t b) { return a | b; }), 63);
 }
-
 __device__ __forceinline__ uint32_t wave_add_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+    return read_lane(wave_scan_incl(v, 0u, [](uint32_t a, uint32_t b) { return a + b; }), 63);
 }
 
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (l >= (uint32_t)d) v += o;
-    }
-    return v;
+    return wave_scan_incl(v, 0u, [](uint32_t a, uint32_t b) { return a + b; });
 }
 
 // ---------------------------------------------------------------------------
@@ -123,24 +152,7 @@ __device__ __forceinline__ uint32_t zcomb(uint32_t far, uint32_t near) {
 
 // inclusive forward scan: result at lane l covers lanes 0..l, open side = after lane l
 __device__ __forceinline__ uint32_t wave_zscan_fwd(uint32_t v) {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (l >= (uint32_t)d) v = zcomb(o, v);
-    }
-    return v;
-}
-
-// inclusive backward scan: result at lane l covers lanes l..63, open side = before lane l
-__device__ __forceinline__ uint32_t wave_zscan_bwd(uint32_t v) {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_down((int)v, d, 64);
-        if (l + (uint32_t)d < 64u) v = zcomb(o, v);
-    }
-    return v;
+    return wave_scan_incl(v, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
 }
 
 // ---------------------------------------------------------------------------

@@ -77,7 +77,7 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
         uint32_t rows = kZAll | 1024u;
         if (nonall) {
             const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
-            rows = 16u * (63u - ph) + (uint32_t)__shfl((int)trail, (int)ph, 64);
+            rows = 16u * (63u - ph) + read_lane(trail, ph);  // ph comes from a ballot: wave-uniform
         }
         carry = zcomb(carry, rows);
     }
@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
         uint32_t rows = kZAll | 1024u;
         if (nonall) {
             const uint32_t ql = (uint32_t)__builtin_ctzll(nonall);
-            rows = 16u * ql + (uint32_t)__shfl((int)lead, (int)ql, 64);
+            rows = 16u * ql + read_lane(lead, ql);
         }
         carry = zcomb(carry, rows);
     }
@@ -111,16 +111,12 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
     // fold the 16 wave summaries: lane i < 16 takes wave i's, 4-step scans, then pick this wave's neighbours
     uint32_t sf = l < (uint32_t)kEncWaves ? scratch[l] : kZIdentity;
     uint32_t sb = l < (uint32_t)kEncWaves ? scratch[kEncWaves + l] : kZIdentity;
-#pragma unroll
-    for (int dd = 1; dd < kEncWaves; dd <<= 1) {
-        const uint32_t of = (uint32_t)__shfl_up((int)sf, dd, 64);
-        const uint32_t ob = (uint32_t)__shfl_down((int)sb, dd, 64);
-        if (l >= (uint32_t)dd) sf = zcomb(of, sf);
-        if (l + (uint32_t)dd < (uint32_t)kEncWaves) sb = zcomb(ob, sb);
-    }
-    uint32_t pre = (uint32_t)__shfl((int)sf, (int)(w ? w - 1 : 0), 64);  // everything before this wave
+    static_assert(kEncWaves == 16, "the wave summaries fill exactly one DPP row");
+    sf = row_scan_prefix(sf, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
+    sb = row_scan_suffix(sb, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
+    uint32_t pre = read_lane(sf, w ? w - 1 : 0);  // everything before this wave
     if (w == 0) pre = kZIdentity;
-    uint32_t post = (uint32_t)__shfl((int)sb, (int)(w + 1 < (uint32_t)kEncWaves ? w + 1 : w), 64);  // everything after it
+    uint32_t post = read_lane(sb, w + 1 < (uint32_t)kEncWaves ? w + 1 : w);  // everything after it
     if (w + 1 == (uint32_t)kEncWaves) post = kZIdentity;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -149,7 +145,7 @@ constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + 
 __device__ __forceinline__ bool wave_may_have_tokens(uint32_t segmask, const LaneBlock& L) {
     const uint32_t w = thread_id() >> 6;
     if ((segmask >> w) & 1u) return true;
-    const uint32_t zb0 = (uint32_t)__shfl((int)L.zb[0], 0, 64);  // zeros before the wave's first byte
+    const uint32_t zb0 = read_lane(L.zb[0], 0);  // zeros before the wave's first byte
     const uint32_t q = (zb0 >= kRunCap) + (zb0 >= 2 * kRunCap) + (zb0 >= 3 * kRunCap);
     const uint32_t r = zb0 - q * kRunCap;
     const uint32_t icap = r ? kRunCap - r : 0u;  // first byte of the segment at which a token starts
@@ -254,9 +250,9 @@ constexpr int kTreeWaves = 4;
 constexpr uint32_t kKeyMax = 0xFFFFFFFFu;
 
 struct TreeLds {
-    uint32_t key[9 * 64];  // node keys: count<<10 | (1023 - index); index order = creation order
-    uint32_t up[2 * kNumSym];     // parent | isB<<10 | add<<11
-    uint16_t sbits[2 * kNumSym];  // description bits of the subtree
+    uint32_t key[5 * 64];         // leaf keys: count<<10 | (1023 - index); index order = creation order
+    uint32_t lcnt[2 * kNumSym];   // leaves in the subtree of each node
+    uint32_t up[2 * kNumSym];     // parent | isB<<10 | sibling<<11 (sibling = child_a, kept for child_b only)
     uint16_t leafsym[kSymStride];
     uint32_t tdesc[kTdescWords];
     uint32_t lhist[kSymStride];  // token histogram of this wave's block
@@ -325,7 +321,7 @@ __device__ __forceinline__ void small_block_hist(const uint8_t* __restrict__ in,
                         first = false;
                     }
                     const uint32_t pl = 63u - (uint32_t)__builtin_clzll(nzb);
-                    const uint32_t lastlit = (uint32_t)__shfl((int)last_nz, (int)pl, 64);
+                    const uint32_t lastlit = read_lane(last_nz, pl);  // pl from a ballot: wave-uniform
                     pend = row_valid - (16u * pl + lastlit + 1u);
                 }
             }
@@ -334,10 +330,11 @@ __device__ __forceinline__ void small_block_hist(const uint8_t* __restrict__ in,
     if (pend && l == 0) run_count(h, pend);
 }
 
-// The merge loop with the live keys in NREG registers per lane (node i lives
-// in lane i&63, register i>>6).  Each iteration extracts the two smallest keys
-// = the reference's `<=` scan (hzr_encode.c:251-260): count ascending, index
-// descending.
+// The merge loop with the live keys in NREG = ceil(S/64) registers per lane.  Each iteration extracts the
+// two smallest keys = the reference's `<=` scan (hzr_encode.c:251-260): count ascending, index descending.
+// The key carries the node index, so where a key is parked is free: the parent takes the register slot of
+// its second child and the slot of the first one stays empty; S slots are enough for the whole build.
+// Nothing is read back from LDS inside the loop (lane 0 only posts the two up-links).
 template <int NREG>
 __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
     const uint32_t l = lane_id();
@@ -355,19 +352,14 @@ __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
 #pragma unroll
         for (int r = 1; r < NREG; ++r) m = min(m, kreg[r]);
         const uint32_t m2 = wave_min_u32(m);
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m2 ? kKeyMax : kreg[r];
-        const uint32_t i1 = 1023u - (m1 & 1023u), i2 = 1023u - (m2 & 1023u);
         const uint32_t n = S + it;
         const uint32_t nk = (((m1 >> 10) + (m2 >> 10)) << 10) | (1023u - n);
 #pragma unroll
-        for (int r = 0; r < NREG; ++r)
-            if ((n >> 6) == (uint32_t)r && (n & 63u) == l) kreg[r] = nk;
+        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m2 ? nk : kreg[r];
+        const uint32_t i1 = 1023u - (m1 & 1023u), i2 = 1023u - (m2 & 1023u);
         if (l == 0) {
-            const uint32_t sb1 = t.sbits[i1], sb2 = t.sbits[i2];
-            t.sbits[n] = (uint16_t)(1u + sb1 + sb2);
-            t.up[i1] = n | (0u << 10) | (1u << 11);          // child_a: code bit 0
-            t.up[i2] = n | (1u << 10) | ((1u + sb1) << 11);  // child_b: code bit 1, described after a's subtree
+            t.up[i1] = n;                             // child_a: code bit 0, described right after the branch bit
+            t.up[i2] = n | (1u << 10) | (i1 << 11);  // child_b: code bit 1, described after child_a's subtree
         }
     }
 }
@@ -430,7 +422,8 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     }
 
     // ---- node arrays -------------------------------------------------------
-    for (uint32_t i = l; i < 9 * 64; i += 64) t.key[i] = kKeyMax;
+    for (uint32_t i = l; i < 5 * 64; i += 64) t.key[i] = kKeyMax;
+    for (uint32_t i = l; i < 2u * kNumSym; i += 64) t.lcnt[i] = i < S ? 1u : 0u;
     for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) t.tdesc[i] = 0;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -438,7 +431,6 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     for (int r = 0; r < 5; ++r) {
         if (cnt[r]) {
             t.key[idx[r]] = (cnt[r] << 10) | (1023u - idx[r]);
-            t.sbits[idx[r]] = 10;  // leaf = '1' + 9-bit symbol
             t.leafsym[idx[r]] = (uint16_t)(r * 64 + l);
         }
     }
@@ -446,30 +438,41 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t nnodes = 2 * S - 1;
-    const uint32_t nreg = (nnodes + 63) >> 6;
+    const uint32_t nreg = (S + 63) >> 6;
     if (nreg <= 1)
         merge_loop<1>(t, S);
     else if (nreg <= 2)
         merge_loop<2>(t, S);
     else if (nreg <= 3)
         merge_loop<3>(t, S);
-    else if (nreg <= 5)
-        merge_loop<5>(t, S);
     else
-        merge_loop<9>(t, S);
+        merge_loop<5>(t, S);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- leaves under every internal node: each leaf credits its ancestors ----
+    const uint32_t root = nnodes - 1;
+    for (uint32_t i = l; i < S; i += 64) {
+        uint32_t cur = i, guard = 0;
+        while (cur != root && guard++ < 64) {  // depth <= 22 for <= 65536 tokens; the bound only guards against a corrupted link
+            cur = t.up[cur] & 1023u;
+            atomicAdd(&t.lcnt[cur], 1u);
+        }
+    }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
 
     // ---- per-leaf walk to the root: code, length, description offset -------
-    const uint32_t root = nnodes - 1;
-    const uint32_t tree_bits = t.sbits[root];
+    // a subtree with L leaves is described in 10 L + (L - 1) bits (leaf = '1' + 9-bit symbol, branch = '0')
+    const uint32_t tree_bits = 11u * S - 1u;
     uint32_t bits_sum = 0;
     for (uint32_t i = l; i < S; i += 64) {
         uint32_t cur = i, code = 0, len = 0, off = 0;
-        while (cur != root && len < 64) {  // depth <= 22 for <= 65536 tokens; the bound only guards against a corrupted link
+        while (cur != root && len < 64) {
             const uint32_t u = t.up[cur];
-            code = (code << 1) | ((u >> 10) & 1u);
-            off += u >> 11;
+            const uint32_t is_b = (u >> 10) & 1u;
+            code = (code << 1) | is_b;
+            off += is_b ? 11u * t.lcnt[u >> 11] : 1u;  // '0' of the branch (+ all of child_a's subtree: 1 + 11 L - 1)
             ++len;
             cur = u & 1023u;
         }
@@ -844,7 +847,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         for (int r = 0; r < 4; ++r) {
             const uint32_t inc = wave_scan_add(nbits[r]);
             excl[r] = run + inc - nbits[r];
-            run += (uint32_t)__shfl((int)inc, 63, 64);
+            run += read_lane(inc, 63);
         }
         if (l == 0) d.wsum[w] = run;
         __syncthreads();
@@ -1109,7 +1112,7 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
                         }
                         const uint32_t inc = wave_scan_add(nbits);
                         const uint32_t mypos = bitpos + inc - nbits;
-                        bitpos += (uint32_t)__shfl((int)inc, 63, 64);
+                        bitpos += read_lane(inc, 63);
                         // pass B: emit
                         if (nbits) {
                             LinSink sink;
@@ -1130,7 +1133,7 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
                         }
                         // zeros behind the row's last literal stay pending
                         const uint32_t pl = 63u - (uint32_t)__builtin_clzll(nzb);
-                        const uint32_t lastlit = (uint32_t)__shfl((int)last_nz, (int)pl, 64);
+                        const uint32_t lastlit = read_lane(last_nz, pl);  // pl from a ballot: wave-uniform
                         pend = row_valid - (16u * pl + lastlit + 1u);
                     }
                 }
