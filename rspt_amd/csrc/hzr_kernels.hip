@@ -208,15 +208,23 @@ __device__ __forceinline__ bool next_work(uint32_t* counter, uint32_t total, con
     return true;
 }
 
+// Every wave counts the tokens that START in its own 4 KiB segment into its own LDS histogram.  Two results:
+//   hist     [hb][264] u32     the block's histogram (sum of the 16), input of k_tree
+//   seghist  [hb][16][264] u16 the per-segment histograms: with the code lengths they give k_tree the stream bit
+//                              at which each segment's tokens start, so k_encode needs no bit-count pass and no
+//                              cross-wave prefix of its own (a 4 KiB segment holds <= 4096 tokens: u16 is enough)
+constexpr uint32_t kSegHistStride = kEncWaves * kSymStride;  // u16 elements per hzr block
+
 __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist, uint32_t* __restrict__ counter,
-                                                     uint32_t total) {
-    __shared__ uint32_t s_hist[kSymStride];
+                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
+                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total) {
+    __shared__ uint32_t s_hist[kEncWaves][kSymStride];
     __shared__ uint32_t s_scr[2 * kEncWaves];
     __shared__ uint32_t s_slot;
-    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&s_hist[0][0])[i] = 0;
     WorkItem wi;
     for (uint32_t pass = 0; next_work(counter, total, g, &s_slot, wi, pass); ++pass) {
+        const uint32_t tid = thread_id();
         const uint32_t j = wi.j, k = wi.k, b = wi.b;
         const uint32_t hb = hb_index(g, b, k, j);
         const uint32_t nbu = nbuse[b];
@@ -225,21 +233,33 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         if ((uint32_t)__popc(segmask) <= kSmallSegments) continue;  // all zero (k_tree: Fill(0)) or small (k_tree takes the histogram itself)
         const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
         const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-        if (tid < kSymStride) s_hist[tid] = 0;
         LaneBlock L;
-        load_and_chain(in, in_size, segmask, L, s_scr);  // contains the barrier that publishes the zeroed histogram
+        load_and_chain(in, in_size, segmask, L, s_scr);  // (its barriers also order the zeroing below against this block's adds)
         if (wave_may_have_tokens(segmask, L)) {
+            uint32_t* myhist = s_hist[tid >> 6];
             GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
-                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), s_hist);
+                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
                 q0 = q1;
                 q1 = q2;
                 q2 = q3;
             }
         }
         __syncthreads();
-        if (tid < kSymStride) hist[(size_t)hb * kSymStride + tid] = s_hist[tid];
+        if (tid < (uint32_t)kSymStride) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int wv = 0; wv < kEncWaves; ++wv) t += s_hist[wv][tid];
+            hist[(size_t)hb * kSymStride + tid] = t;
+        }
+        uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2);
+        for (uint32_t d = tid; d < kSegHistStride / 2; d += kEncThreads) {
+            const uint32_t lo = (&s_hist[0][0])[2 * d], hi = (&s_hist[0][0])[2 * d + 1];
+            sh[d] = lo | (hi << 16);
+        }
+        __syncthreads();  // everyone has read the histograms
+        for (uint32_t i = tid; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&s_hist[0][0])[i] = 0;
     }
 }
 
@@ -367,7 +387,8 @@ __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
 __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, const uint8_t* __restrict__ planes, Geom g,
                                                          const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
                                                          uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
-                                                         BlockMeta* __restrict__ meta) {
+                                                         BlockMeta* __restrict__ meta, const uint32_t* __restrict__ seghist,
+                                                         uint32_t* __restrict__ segbase) {
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
@@ -386,7 +407,9 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     }
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     uint32_t* h = t.lhist;
-    if ((uint32_t)__popc(segmask) <= kSmallSegments) {  // small block: this wave takes the histogram itself
+    const bool own_hist = (uint32_t)__popc(segmask) <= kSmallSegments;
+    if (l == 0) segbase[(size_t)hb * kEncWaves] = 0xFFFFFFFFu;  // "no segment offsets" unless set below
+    if (own_hist) {  // small block: this wave takes the histogram itself
         for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
@@ -478,6 +501,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         }
         const uint32_t sym = t.leafsym[i];
         cwo[sym] = code | (len << 24);
+        t.key[sym] = len + run_extra_bits(sym);  // stream bits per token of this symbol (the key slots are free now)
         // description: '1' then the 9-bit symbol, LSB first (hzr_encode.c:184-191)
         const uint32_t v = 1u | (sym << 1);
         const uint32_t wi = off >> 5, sh = off & 31u;
@@ -491,14 +515,40 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     __builtin_amdgcn_wave_barrier();
     uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
     for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
+    const uint32_t total_bits = tree_bits + bits_sum;
+    const uint32_t nbytes = (total_bits + 7) >> 3;
+    // Huffman iff the payload fits in in_size bytes and is < 65536 (hzr_encode.c:377-382,463-469)
+    const bool huff = nbytes <= in_size && nbytes < kHzrBlock;
     if (l == 0) {
-        const uint32_t total_bits = tree_bits + bits_sum;
-        const uint32_t nbytes = (total_bits + 7) >> 3;
-        // Huffman iff the payload fits in in_size bytes and is < 65536 (hzr_encode.c:377-382,463-469)
-        if (nbytes <= in_size && nbytes < kHzrBlock)
+        if (huff)
             meta[hb] = BlockMeta{kModeHuff, nbytes, tree_bits, ntok};  // (fill is unused in this mode: it carries the token count)
         else
             meta[hb] = BlockMeta{kModeCopy, in_size, 0, 0};
+    }
+    if (!huff || own_hist) return;
+
+    // ---- stream bit at which the tokens of each 4 KiB segment start (k_hist's per-segment histograms x code lengths) ----
+    // lane l: segment l / 4, quarter l % 4 of its 132 u16 pairs
+    {
+        const uint32_t seg = l >> 2, part = l & 3u;
+        const uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2) + seg * (kSymStride / 2) + part * 33u;
+        uint32_t pr[33];
+#pragma unroll
+        for (int i = 0; i < 33; ++i) pr[i] = sh[i];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 33; ++i) {
+            const uint32_t s0 = 2u * (part * 33u + (uint32_t)i);
+            // unused symbols (and the padding past 260) have count 0: whatever their cost slots hold is multiplied away
+            acc += (pr[i] & 0xFFFFu) * t.key[s0];
+            acc += (pr[i] >> 16) * t.key[s0 + 1u];
+        }
+        acc += dpp<0xB1>(0u, acc);  // quad_perm [1,0,3,2]
+        acc += dpp<0x4E>(0u, acc);  // quad_perm [2,3,0,1]: every lane of the quad holds the segment's bits
+        // exclusive prefix over the 16 segments (one value per quad): scan with the quad's bits counted once
+        const uint32_t mine = part == 0 ? acc : 0u;
+        const uint32_t incl = wave_scan_add(mine);
+        if (part == 0) segbase[(size_t)hb * kEncWaves + seg] = 32u + tree_bits + incl - mine;  // the payload starts at image byte 4
     }
 }
 
@@ -615,12 +665,12 @@ constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logic
 constexpr uint32_t kStagePhys = kStageWords + (kStageWords >> 4) + 2;   // physical words
 
 struct EncLds {
-    uint32_t stage[kStagePhys];
-    uint32_t cw[kSymStride];
+    uint32_t cw[kSymStride];  // first: the lookups address it with an immediate offset (16 bits)
     uint32_t crc[4][256];
     uint32_t scr[2 * kEncWaves];
     uint32_t wsum[kEncWaves];
     uint32_t crc_out;
+    uint32_t stage[kStagePhys];
 };
 
 struct BitSink {
@@ -677,16 +727,96 @@ __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint3
     return nb;
 }
 
-// pass 2: emit the codes of this granule's tokens at stream bit `bitpos` (hzr_encode.c:410-457).
-// Tokens without extra bits (literals, 1- and 2-zero runs) are looked up by index and go two
-// at a time (one flush test per pair); the 8 lookups of a half-granule are issued together.
-// A pair that holds a longer run token (rare in dense planes) takes the general path.
-__device__ __forceinline__ void emit_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
-                                             const uint32_t* s_cw, uint32_t* stage, uint32_t bitpos) {
+// OR `len` (<= 32) bits of v into the image at bit `pos`
+__device__ __forceinline__ void or_bits32(uint32_t* stage, uint32_t& pos, uint32_t v, uint32_t len) {
+    const uint32_t word = pos >> 5, sh = pos & 31u;
+    const uint64_t sv = (uint64_t)v << sh;
+    atomicOr(&stage[skew(word)], (uint32_t)sv);
+    if (sh + len > 32) atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
+    pos += len;
+}
+
+// OR up to 64 bits (hi:lo) into the image at bit `pos`: three words, unconditionally (zeros are harmless and
+// with 64 lanes some lane needs each of them anyway)
+__device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi) {
+    const uint32_t word = pos >> 5, sh = pos & 31u;
+    const uint64_t sv = (((uint64_t)hi << 32) | lo) << sh;
+    atomicOr(&stage[skew(word)], (uint32_t)sv);
+    atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
+    atomicOr(&stage[skew(word + 2)], (hi >> 1) >> (31u - sh));
+}
+
+// The token that starts at byte i of a granule as one bit string: code, then the run's extra bits
+// (hzr_encode.c:422-447).  <= 24 + 14 bits.
+__device__ __forceinline__ void token_at(uint32_t i, const GranuleMasks& m, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t zm,
+                                         uint32_t nv, uint32_t za, const uint32_t* s_cw, uint32_t& lo, uint32_t& hi, uint32_t& len) {
+    const bool is_run = (m.runs >> i) & 1u;
+    const uint32_t z = run_token_length(zm, nv, za, i);
+    const uint32_t sym = is_run ? run_symbol(z) : (granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8));
+    const uint32_t cr = s_cw[sym];
+    const uint32_t cl = cr >> 24;
+    const uint32_t eb = is_run ? run_extra_bits(sym) : 0u;
+    const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)(is_run ? run_extra_value(sym, z) : 0u) << cl);
+    lo = (uint32_t)v;
+    hi = (uint32_t)(v >> 32);
+    len = cl + eb;
+}
+
+// OR one token (<= 38 bits) into the image at bit `pos`
+__device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t len) {
+    const uint32_t word = pos >> 5, sh = pos & 31u;
+    const uint64_t sv = (((uint64_t)hi << 32) | lo) << sh;
+    atomicOr(&stage[skew(word)], (uint32_t)sv);
+    atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
+    if (sh + len > 64) atomicOr(&stage[skew(word + 2)], (hi >> 1) >> (31u - sh));
+}
+
+// One row (a granule per lane, 1 KiB per wave) from lookup to image in a single pass (hzr_encode.c:410-457).
+// `base` = stream bit at which this row's tokens start (k_tree's segment offset plus the rows before); a wave
+// scan of the lanes' bit totals places every lane.  Two wave-uniform shapes:
+//   sparse  no lane holds more than kRowSlots tokens: the tokens are taken one per lane and step, kept in
+//           registers across the scan, and OR-ed into the image
+//   dense   the codes of four adjacent tokens without extra bits (literals, 1- and 2-zero runs) are joined into
+//           one <= 64-bit string per quad of bytes and OR-ed with three LDS atomics; a quad that holds a run token
+//           with extra bits, or a pair of codes longer than 32 bits (both rare in dense planes), is counted
+//           here and emitted token by token afterwards.
+constexpr int kRowSlots = 4;
+
+__device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
+                                         const uint32_t* s_cw, uint32_t* stage, uint32_t& base) {
     const GranuleMasks m = granule_masks(zm, nv, zb, za);
+    const uint32_t tokmask = m.single | m.runs;
+    if (!__ballot(tokmask != 0)) return;  // no token starts in this row
+
+    if (!__ballot(__popc(tokmask) > kRowSlots)) {
+        uint32_t tlo[kRowSlots], thi[kRowSlots], tlen[kRowSlots];
+        uint32_t t = tokmask, tot = 0;
+#pragma unroll
+        for (int sl = 0; sl < kRowSlots; ++sl) {
+            tlo[sl] = thi[sl] = tlen[sl] = 0;
+            if (__ballot(t != 0)) {
+                if (t) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(t);
+                    t &= t - 1;
+                    token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, tlo[sl], thi[sl], tlen[sl]);
+                    tot += tlen[sl];
+                }
+            }
+        }
+        const uint32_t inc = wave_scan_add(tot);
+        uint32_t pos = base + inc - tot;
+        base += read_lane(inc, 63);
+#pragma unroll
+        for (int sl = 0; sl < kRowSlots; ++sl) {
+            if (tlen[sl]) or_token(stage, pos, tlo[sl], thi[sl], tlen[sl]);
+            pos += tlen[sl];
+        }
+        return;
+    }
+
     const uint32_t w[4] = {w0, w1, w2, w3};
-    BitSink sink;
-    sink.start(stage, bitpos);
+    uint32_t qlo[4], qhi[4], qlen[4];
+    uint32_t slow = 0;
 #pragma unroll
     for (uint32_t h = 0; h < 16; h += 8) {
         uint32_t c[8];
@@ -694,37 +824,57 @@ __device__ __forceinline__ void emit_granule(uint32_t w0, uint32_t w1, uint32_t 
         for (uint32_t i = 0; i < 8; ++i) c[i] = s_cw[((w[(h + i) >> 2] >> (((h + i) & 3) * 8)) & 0xFFu) | (((m.two >> (h + i)) & 1u) << 8)];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (uint32_t i = 0; i < 8; i += 2) {
-            const uint32_t p0 = h + i, p1 = h + i + 1;
-            const uint32_t c0 = ((m.single >> p0) & 1u) ? c[i] : 0u;
-            const uint32_t c1 = ((m.single >> p1) & 1u) ? c[i + 1] : 0u;
-            if ((m.runs >> p0) & 3u) {
+        for (uint32_t qq = 0; qq < 2; ++qq) {
+            const uint32_t qd = (h >> 2) + qq, p = 4 * qd;
+            uint32_t cc[4];
 #pragma unroll
-                for (uint32_t e = p0; e <= p1; ++e) {
-                    const uint32_t ce = e == p0 ? c0 : c1;
-                    if ((m.runs >> e) & 1u) {
-                        const uint32_t z = run_token_length(zm, nv, za, e);
-                        const uint32_t sym = run_symbol(z);
-                        const uint32_t cr = s_cw[sym];
-                        sink.put(cr & 0x00FFFFFFu, cr >> 24);            // code first ...
-                        const uint32_t eb = run_extra_bits(sym);
-                        if (eb) sink.put(run_extra_value(sym, z), eb);  // ... then the run's extra bits
-                    } else {
-                        sink.put(ce & 0x00FFFFFFu, ce >> 24);
-                    }
-                }
-            } else {
-                const uint32_t l0 = c0 >> 24, l1 = c1 >> 24;
-                if (l0 + l1 <= 32) {
-                    sink.put((c0 & 0x00FFFFFFu) | ((c1 & 0x00FFFFFFu) << l0), l0 + l1);
-                } else {
-                    sink.put(c0 & 0x00FFFFFFu, l0);
-                    sink.put(c1 & 0x00FFFFFFu, l1);
+            for (uint32_t i = 0; i < 4; ++i)  // keep the word only where a token without extra bits starts (bit -> all-ones mask)
+                cc[i] = c[4 * qq + i] & (uint32_t)__builtin_amdgcn_sbfe((int)m.single, p + i, 1);
+            const uint32_t l0 = cc[0] >> 24, l1 = cc[1] >> 24, l2 = cc[2] >> 24, l3 = cc[3] >> 24;
+            const uint32_t s1 = l0 + l1, s2 = l2 + l3;
+            const uint32_t v01 = (cc[0] & 0x00FFFFFFu) | ((cc[1] & 0x00FFFFFFu) << l0);
+            const uint32_t v23 = (cc[2] & 0x00FFFFFFu) | ((cc[3] & 0x00FFFFFFu) << l2);
+            const uint64_t V = (uint64_t)v01 | ((uint64_t)v23 << s1);
+            qlo[qd] = (uint32_t)V;
+            qhi[qd] = (uint32_t)(V >> 32);
+            qlen[qd] = s1 + s2;
+            const uint32_t r4 = (m.runs >> p) & 0xFu;
+            if (r4 | (uint32_t)(s1 > 32) | (uint32_t)(s2 > 32)) {
+                slow |= 0xFu << p;  // the quad's four bytes
+                uint32_t st = r4 << p;
+                while (st) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(st);
+                    st &= st - 1;
+                    const uint32_t sym = run_symbol(run_token_length(zm, nv, za, i));
+                    qlen[qd] += (s_cw[sym] >> 24) + run_extra_bits(sym);
                 }
             }
         }
     }
-    sink.flush();
+    const uint32_t tot = qlen[0] + qlen[1] + qlen[2] + qlen[3];
+    const uint32_t inc = wave_scan_add(tot);
+    uint32_t pq[4];
+    pq[0] = base + inc - tot;
+    pq[1] = pq[0] + qlen[0];
+    pq[2] = pq[1] + qlen[1];
+    pq[3] = pq[2] + qlen[2];
+    base += read_lane(inc, 63);
+#pragma unroll
+    for (uint32_t qd = 0; qd < 4; ++qd)
+        if (qlen[qd] && !((slow >> (4 * qd)) & 1u)) or_bits64(stage, pq[qd], qlo[qd], qhi[qd]);
+    uint32_t ts = tokmask & slow;  // the tokens of the slow quads, one by one
+    uint32_t prevq = 4, pp = 0;
+    while (ts) {
+        const uint32_t i = (uint32_t)__builtin_ctz(ts);
+        ts &= ts - 1;
+        const uint32_t qd = i >> 2;
+        if (qd != prevq) pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
+        prevq = qd;
+        uint32_t lo, hi, len;
+        token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, lo, hi, len);
+        or_token(stage, pp, lo, hi, len);
+        pp += len;
+    }
 }
 
 // byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
@@ -760,7 +910,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
                                              const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                              const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
                                              uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate_arg,
-                                             unsigned long long* __restrict__ stamps) {
+                                             unsigned long long* __restrict__ stamps, const uint32_t* __restrict__ segbase) {
     EncLds& d = g_enc;
     const uint32_t ablate = DIAG ? ablate_arg : 0u;  // the production instantiation carries no diagnostic code
     // diagnostic (ablate bit 7): lane 0 of every wave of 512 hzr blocks (window ablate>>16) stores s_memtime at section seams
@@ -818,6 +968,8 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
         if (tid < kSymStride) d.cw[tid] = cw[(size_t)hb * kSymStride + tid];
         LaneBlock B;
+        const uint32_t first_base = segbase[(size_t)hb * kEncWaves];  // 0xFFFFFFFF: no offsets from k_tree (its own-histogram blocks)
+        uint32_t base = segbase[(size_t)hb * kEncWaves + w];           // stream bit at which this wave's tokens start
         load_and_chain(in, in_size, segmask, B, d.scr);  // barriers inside publish cw and the zeroed image
         if (ablate & 32u) return;
         RSPT_STAMP(1);
@@ -825,49 +977,33 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         if (tid < twords) atomicOr(&d.stage[skew(1 + tid)], tdesc[(size_t)hb * kTdescWords + tid]);
         const bool active = wave_may_have_tokens(segmask, B);  // wave-uniform
         GranuleRegs q0 = granule_regs(B, 0), q1 = granule_regs(B, 1), q2 = granule_regs(B, 2), q3 = granule_regs(B, 3);
-        uint32_t nbits[4] = {0, 0, 0, 0};
+        if (first_base == 0xFFFFFFFFu) {
+            // the block's histogram was taken by k_tree in one piece: count this wave's bits here and take the prefix
+            // over the waves (blocks with at most kSmallSegments non-zero segments that were too big for k_encode_small)
+            uint32_t wbits = 0;
 #pragma unroll 1
-        for (int r = 0; r < 4 && active; ++r) {  // rolled: granules and results rotate through fixed registers
-            const uint32_t nbv = (ablate & 4u) ? 100u : bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw);
-            const GranuleRegs t = q0;
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
-            q3 = t;
-            nbits[0] = nbits[1];
-            nbits[1] = nbits[2];
-            nbits[2] = nbits[3];
-            nbits[3] = nbv;
+            for (int r = 0; r < 4 && active; ++r) {  // rolled: granules rotate through fixed registers
+                wbits += bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw);
+                const GranuleRegs t = q0;
+                q0 = q1;
+                q1 = q2;
+                q2 = q3;
+                q3 = t;
+            }
+            wbits = wave_add_u32(wbits);
+            if (l == 0) d.wsum[w] = wbits;
+            __syncthreads();
+            base = 32u + m.tree_bits;  // the payload starts at logical byte 4
+            for (uint32_t i = 0; i < w; ++i) base += d.wsum[i];
         }
         RSPT_STAMP(2);
-        // exclusive bit offsets in byte order: wave w rows 0..3, lanes 0..63
-        uint32_t excl[4];
-        uint32_t run = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t inc = wave_scan_add(nbits[r]);
-            excl[r] = run + inc - nbits[r];
-            run += read_lane(inc, 63);
-        }
-        if (l == 0) d.wsum[w] = run;
-        __syncthreads();
-        uint32_t wbase = 32u + m.tree_bits;  // the payload starts at logical byte 4
-        for (uint32_t i = 0; i < w; ++i) wbase += d.wsum[i];
         RSPT_STAMP(3);
-        uint32_t pos0 = wbase + excl[0], pos1 = wbase + excl[1], pos2 = wbase + excl[2], pos3 = wbase + excl[3];
-        uint32_t nz0 = nbits[0], nz1 = nbits[1], nz2 = nbits[2], nz3 = nbits[3];
 #pragma unroll 1
-        for (int r = 0; r < 4 && active; ++r) {  // after four rotations q0..q3 are back in order
-            if (nz0 && !(ablate & 1u)) emit_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.stage, pos0);
+        for (int r = 0; r < 4 && active && !(ablate & 1u); ++r) {
+            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.stage, base);
             q0 = q1;
             q1 = q2;
             q2 = q3;
-            pos0 = pos1;
-            pos1 = pos2;
-            pos2 = pos3;
-            nz0 = nz1;
-            nz1 = nz2;
-            nz2 = nz3;
         }
     } else {
         // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
@@ -1179,7 +1315,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
                                                           const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                           uint32_t ablate, unsigned long long* __restrict__ stamps, WorkQueues* __restrict__ wq,
-                                                          const uint32_t* __restrict__ big_list) {
+                                                          const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase) {
     __shared__ uint32_t s_slot;
     (&g_enc.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
     const uint32_t n_big = wq->n_big;
@@ -1193,7 +1329,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         if (i >= n_big) break;
         const uint32_t hb = big_list[i];
         const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
-        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps);
+        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps, segbase);
     }
 }
 
