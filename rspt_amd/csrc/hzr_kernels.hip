@@ -664,12 +664,20 @@ __device__ __forceinline__ uint32_t skew(uint32_t w) { return w + (w >> 4); }
 constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logical words (X + payload + read slack)
 constexpr uint32_t kStagePhys = kStageWords + (kStageWords >> 4) + 2;   // physical words
 
+constexpr uint32_t kRunClsEntries = 280;  // lengths 0..278 and ">= 279" (hzr_internal.h:117-121)
+__device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
+    const uint32_t sym = run_symbol(z);
+    const uint32_t base = sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : sym == 260 ? 279u : 0u;
+    return sym | (run_extra_bits(sym) << 12) | (base << 16);
+}
+
 struct EncLds {
     uint32_t cw[kSymStride];  // first: the lookups address it with an immediate offset (16 bits)
     uint32_t crc[4][256];
     uint32_t scr[2 * kEncWaves];
     uint32_t wsum[kEncWaves];
     uint32_t crc_out;
+    uint32_t runcls[kRunClsEntries];  // zero-run length -> symbol | extra bits << 12 | first length of the class << 16
     uint32_t stage[kStagePhys];
 };
 
@@ -749,14 +757,17 @@ __device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_
 // The token that starts at byte i of a granule as one bit string: code, then the run's extra bits
 // (hzr_encode.c:422-447).  <= 24 + 14 bits.
 __device__ __forceinline__ void token_at(uint32_t i, const GranuleMasks& m, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t zm,
-                                         uint32_t nv, uint32_t za, const uint32_t* s_cw, uint32_t& lo, uint32_t& hi, uint32_t& len) {
+                                         uint32_t nv, uint32_t za, const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t& lo, uint32_t& hi,
+                                         uint32_t& len) {
     const bool is_run = (m.runs >> i) & 1u;
     const uint32_t z = run_token_length(zm, nv, za, i);
-    const uint32_t sym = is_run ? run_symbol(z) : (granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8));
-    const uint32_t cr = s_cw[sym];
+    const uint32_t e = s_runcls[min(z, kRunClsEntries - 1u)];
+    const uint32_t lit = granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8);
+    const uint32_t cr = s_cw[is_run ? (e & 0xFFFu) : lit];
     const uint32_t cl = cr >> 24;
-    const uint32_t eb = is_run ? run_extra_bits(sym) : 0u;
-    const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)(is_run ? run_extra_value(sym, z) : 0u) << cl);
+    const uint32_t eb = is_run ? ((e >> 12) & 0xFu) : 0u;
+    const uint32_t xv = is_run ? z - (e >> 16) : 0u;
+    const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)xv << cl);
     lo = (uint32_t)v;
     hi = (uint32_t)(v >> 32);
     len = cl + eb;
@@ -780,10 +791,10 @@ __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t
 //           one <= 64-bit string per quad of bytes and OR-ed with three LDS atomics; a quad that holds a run token
 //           with extra bits, or a pair of codes longer than 32 bits (both rare in dense planes), is counted
 //           here and emitted token by token afterwards.
-constexpr int kRowSlots = 4;
+constexpr int kRowSlots = 8;
 
 __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
-                                         const uint32_t* s_cw, uint32_t* stage, uint32_t& base) {
+                                         const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t* stage, uint32_t& base) {
     const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t tokmask = m.single | m.runs;
     if (!__ballot(tokmask != 0)) return;  // no token starts in this row
@@ -798,7 +809,7 @@ __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, 
                 if (t) {
                     const uint32_t i = (uint32_t)__builtin_ctz(t);
                     t &= t - 1;
-                    token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, tlo[sl], thi[sl], tlen[sl]);
+                    token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, s_runcls, tlo[sl], thi[sl], tlen[sl]);
                     tot += tlen[sl];
                 }
             }
@@ -871,7 +882,7 @@ __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, 
         if (qd != prevq) pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
         prevq = qd;
         uint32_t lo, hi, len;
-        token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, lo, hi, len);
+        token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, s_runcls, lo, hi, len);
         or_token(stage, pp, lo, hi, len);
         pp += len;
     }
@@ -1000,7 +1011,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         RSPT_STAMP(3);
 #pragma unroll 1
         for (int r = 0; r < 4 && active && !(ablate & 1u); ++r) {
-            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.stage, base);
+            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.runcls, d.stage, base);
             q0 = q1;
             q1 = q2;
             q2 = q3;
@@ -1318,6 +1329,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
                                                           const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase) {
     __shared__ uint32_t s_slot;
     (&g_enc.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
+    if (threadIdx.x < kRunClsEntries) g_enc.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     const uint32_t n_big = wq->n_big;
     // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
     // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
