@@ -95,73 +95,139 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     const uint32_t nitems = g.nch * ngrp;
     const uint32_t m_nch = magic_of(g.nch);
     uint32_t mag = 0;
-    for (uint32_t q = tid; q < nitems; q += nthr) {
+    const size_t rstride = (size_t)g.nch * BPS;
+    // an item's 18 samples (16 + the two before them, for the delta and the xor) in registers
+    struct ItemRegs {
+        uint32_t pv[16];
+        uint32_t p1, p2;
+    };
+    auto load_item = [&](uint32_t q, ItemRegs& R) {
         const uint32_t grp = fast_div(q, g.nch, m_nch);
         const uint32_t c = q - grp * g.nch;
         const uint32_t t0 = grp << 4;
         const uint32_t cnt = min(16u, Tn - t0);
         const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
-        const size_t rstride = (size_t)g.nch * BPS;
-        uint32_t pv[16];
         if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
 #pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
+            for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
         } else {
 #pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+            for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
         }
-        uint32_t p1 = 0, oprev = 0;  // p[i-1], o[i-1]
+        R.p1 = R.p2 = 0;
+        if (XDELTA) {
+            if (s0 + t0 >= 2) {  // same channel, two samples back
+                R.p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
+                R.p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
+            } else {  // channel start: the flat array continues from the end of channel c-1
+                const int64_t flat = (int64_t)c * g.ns + s0 + t0;
+                R.p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
+                R.p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
+            }
+        }
+    };
+    // the next item's loads are issued before the current item is transformed: the HBM round trip hides behind
+    // ~250 VALU instructions instead of stalling the wave (8 waves per CU cannot hide it by themselves)
+    ItemRegs cur, nxt;
+    uint32_t q = tid;
+    bool have = q < nitems;
+    if (have) load_item(q, cur);
+    while (have) {
+        const uint32_t qn = q + nthr;
+        const bool have_next = qn < nitems;
+        if (have_next) load_item(qn, nxt);
+        const uint32_t grp = fast_div(q, g.nch, m_nch);
+        const uint32_t c = q - grp * g.nch;
+        const uint32_t t0 = grp << 4;
+        const uint32_t cnt = min(16u, Tn - t0);
+        uint32_t p1 = cur.p1, oprev = 0;  // p[i-1], o[i-1]
         if (XDELTA) {
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
-            uint32_t p2;
-            if (s0 + t0 >= 2) {  // same channel, two samples back
-                p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
-                p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
-            } else {  // channel start: the flat array continues from the end of channel c-1
-                p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
-                p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
-            }
-            oprev = (flat == 0) ? 0u : (p1 - p2 - 128u);  // xor_encode_32 starts from last = 0
+            oprev = (flat == 0) ? 0u : (cur.p1 - cur.p2 - 128u);  // xor_encode_32 starts from last = 0
         }
-        uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        // elements past cnt (last group of a ragged tile only) are computed on zeros and never stored or flagged:
-        // their plane bytes are masked off below
+        const uint32_t* pv = cur.pv;
+        uint32_t vv[16];
+        if (cnt == 16) {  // (all but the last group of a ragged tile)
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) {
-            const uint32_t p = pv[e];
-            uint32_t v;
-            if (XDELTA) {
-                const uint32_t o = p - p1 - 128u;
-                v = o ^ oprev;
-                oprev = o;
-                p1 = p;
-                // sign-extend from the sample width, fold to a magnitude (escalation test)
-                const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
-                mag |= e < cnt ? (uint32_t)(x ^ (x >> 31)) : 0u;
-            } else {
-                v = p;
+            for (uint32_t e = 0; e < 16; ++e) {
+                const uint32_t p = pv[e];
+                if (XDELTA) {
+                    const uint32_t o = p - p1 - 128u;
+                    vv[e] = o ^ oprev;
+                    oprev = o;
+                    p1 = p;
+                    // sign-extend from the sample width, fold to a magnitude (escalation test)
+                    const int32_t x = BPS < 4 ? ((int32_t)(vv[e] << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)vv[e];
+                    mag |= (uint32_t)(x ^ (x >> 31));
+                } else {
+                    vv[e] = p;
+                }
             }
-            v = e < cnt ? v : 0u;
-            const uint32_t sh = (e & 3) * 8;
-            pw[0][e >> 2] |= (v & 0xFFu) << sh;
-            pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
-            pw[2][e >> 2] |= ((v >> 16) & 0xFFu) << sh;
-            pw[3][e >> 2] |= (v >> 24) << sh;
+        } else {
+            // elements past cnt are computed on zeros and never stored or flagged: their plane bytes are masked off
+#pragma unroll
+            for (uint32_t e = 0; e < 16; ++e) {
+                const uint32_t p = pv[e];
+                uint32_t v;
+                if (XDELTA) {
+                    const uint32_t o = p - p1 - 128u;
+                    v = o ^ oprev;
+                    oprev = o;
+                    p1 = p;
+                    const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
+                    mag |= e < cnt ? (uint32_t)(x ^ (x >> 31)) : 0u;
+                } else {
+                    v = p;
+                }
+                vv[e] = e < cnt ? v : 0u;
+            }
         }
-        const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
-        const uint32_t jb = (c * g.ns + s0) >> 16;
+        // byte-plane split of four samples at a time: a 4 x 4 byte transpose in 8 v_perm_b32
+        // (selector bytes 0-3 pick from the second operand, 4-7 from the first)
+        uint32_t pw[4][4];
+#pragma unroll
+        for (uint32_t g4 = 0; g4 < 4; ++g4) {
+            const uint32_t a0 = vv[4 * g4], a1 = vv[4 * g4 + 1], a2 = vv[4 * g4 + 2], a3 = vv[4 * g4 + 3];
+            const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+            const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+            pw[0][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+            pw[1][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+            pw[2][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+            pw[3][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+        }
+        uint32_t nzm = 0;  // bit k: plane k of this item holds a non-zero byte
 #pragma unroll
         for (uint32_t k = 0; k < 4; ++k) {
-            uint4 w = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
-            if (k >= kfirst && k < kfirst + kcount) *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = w;
-            if (!fixup && !(ablate & 65536u) && (w.x | w.y | w.z | w.w)) {  // (an item straddling a segment edge marks both sides: conservative)
-                const uint32_t ja = f0 >> 16, jz = f1 >> 16;
-                const uint32_t ba = 1u << ((f0 >> 12) & 15u), bz = 1u << ((f1 >> 12) & 15u);
-                // (fire-and-forget: a read-before-atomic here would put a dependent HBM round trip into the item loop)
-                if (!(atomicOr(&s_nz[((ja - jb) * 4 + k) * g.nch + c], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
-                if ((jz != ja || bz != ba) && !(atomicOr(&s_nz[((jz - jb) * 4 + k) * g.nch + c], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
+            if (k >= kfirst && k < kfirst + kcount)
+                *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+            nzm |= ((pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0 ? 1u : 0u) << k;
+        }
+        if (!fixup && !(ablate & 65536u) && nzm) {
+            const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
+            const uint32_t jb = (c * g.ns + s0) >> 16;
+            const uint32_t ja = f0 >> 16, jz = f1 >> 16;
+            const uint32_t ba = 1u << ((f0 >> 12) & 15u), bz = 1u << ((f1 >> 12) & 15u);
+            const bool two = jz != ja || bz != ba;  // (an item straddling a segment edge marks both sides: conservative)
+            uint32_t* za = &s_nz[((ja - jb) * 4) * g.nch + c];
+            uint32_t* zz = &s_nz[((jz - jb) * 4) * g.nch + c];
+            // plain reads first (the four of them in one wait): the atomics are needed once per (plane, channel, segment) and tile
+            uint32_t have_a[4], have_z[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                have_a[k] = za[k * g.nch];
+                have_z[k] = two ? zz[k * g.nch] : bz;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (!((nzm >> k) & 1u)) continue;
+                // (fire-and-forget global atomics: the first setter in the workgroup forwards the bit to HBM)
+                if (!(have_a[k] & ba) && !(atomicOr(&za[k * g.nch], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
+                if (two && !(have_z[k] & bz) && !(atomicOr(&zz[k * g.nch], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
             }
         }
+        cur = nxt;
+        q = qn;
+        have = have_next;
     }
     if (XDELTA && !fixup) {
         // only the three thresholds matter (need_from_mask): fold to the top bit of each byte range, and
