@@ -44,7 +44,9 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.LIB
-    if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+    if os.environ.get("RSPT_HIP_LIB"):  # A/B timing of two builds in one session (tools/ab.sh); not a fallback
+        path = os.environ["RSPT_HIP_LIB"]
+    elif os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("rspt_amd: %s is missing and cannot be built here; there is no CPU fallback" % path)

@@ -156,6 +156,10 @@ struct rspt_hip_packer {
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
 
+    // the small-block encoder runs beside the big one (it fills the CUs the persistent grid frees in its tail)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
     // profiling
     bool profiling = false;
     hipEvent_t ev[ST_COUNT + 1] = {};
@@ -260,7 +264,6 @@ int rspt_hip_device_count(void) {
 static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planes);
     hipFree(p->planar);
-    hipFree(p->needmask);
     hipFree(p->nbuse);
     hipFree(p->nzflag);
     hipFree(p->big_list);
@@ -406,7 +409,6 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     make_crc_consts(cc);
     p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&p->work_ctr, 8 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -418,6 +420,12 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         return RSPT_HIP_ERR_LAUNCH;
     }
     for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&p->ev[i]);
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+        rspt_hip_packer_destroy(p);
+        return RSPT_HIP_ERR_LAUNCH;
+    }
     if (kind == RSPT_HIP_KIND_DCT) {
         const double ratio1 = sqrt(2.0 / (double)(int)ns);
         const float cs0 = (float)(1 / sqrt(2));
@@ -481,7 +489,6 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     if (p->stream) hipStreamSynchronize(p->stream);
     free_workspace(p);
     hipFree(p->crc);
-    hipFree(p->work_ctr);
     hipFree(p->stamps);
     hipFree(p->nb_state);
     hipFree(p->cos_tab);
@@ -493,6 +500,12 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_size);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
+    if (p->side) {
+        hipStreamSynchronize(p->side);
+        hipStreamDestroy(p->side);
+    }
+    if (p->ev_fork) hipEventDestroy(p->ev_fork);
+    if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->stream) hipStreamDestroy(p->stream);
     delete p;
 }
@@ -517,9 +530,10 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     const size_t nhb = max_blocks * kMaxPlanes * g.nblk;
     bool ok = true;
     ok &= hipMalloc(&p->planes, max_blocks * kMaxPlanes * g.plane_stride + 4096) == hipSuccess;
-    ok &= hipMalloc(&p->needmask, max_blocks * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
-    ok &= hipMalloc(&p->nzflag, nhb * sizeof(uint32_t)) == hipSuccess;
+    // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
+    // placed per call right behind the part of nzflag in use
+    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 16) * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
@@ -564,9 +578,12 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
 
     stamp(p, ST_PRE, st);
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
-    if (xd) HIPCHK(p, hipMemsetAsync(p->needmask, 0, nblocks * sizeof(uint32_t), st));
-    HIPCHK(p, hipMemsetAsync(p->nzflag, 0, nblocks * kMaxPlanes * g.nblk * sizeof(uint32_t), st));
-    HIPCHK(p, hipMemsetAsync(p->work_ctr, 0, 8 * sizeof(uint32_t), st));
+    {
+        const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
+        p->needmask = p->nzflag + nhb_call;
+        p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
+        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, (size_t)((p->work_ctr + 8) - p->nzflag) * sizeof(uint32_t), st));
+    }
     uint32_t np = 4;
     switch (g.bps) {
         case 1: np = launch_front<1>(p, src, nblocks, st); break;
@@ -617,6 +634,17 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
                        d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list);
 
     stamp(p, ST_ENCODE, st);
+    {
+        // both encoders depend on k_layout only.  The small-block one goes to the side stream: the big one's persistent
+        // workgroups hold every wave slot, so the small blocks start as those retire and fill its tail.
+        HIPCHK(p, hipEventRecord(p->ev_fork, st));
+        HIPCHK(p, hipStreamWaitEvent(p->side, p->ev_fork, 0));
+        const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
+        const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
+        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, p->side, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc,
+                           p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate);
+        HIPCHK(p, hipEventRecord(p->ev_join, p->side));
+    }
     if (p->ablate)
         hipLaunchKernelGGL((k_encode<true>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
                            p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, wq, p->big_list, p->segbase);
@@ -624,12 +652,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         hipLaunchKernelGGL((k_encode<false>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
                            p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, 0u, p->stamps, wq, p->big_list, p->segbase);
     stamp(p, ST_ENCODE_SMALL, st);
-    {
-        const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
-        const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
-        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
-                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate);
-    }
+    HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
