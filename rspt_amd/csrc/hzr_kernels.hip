@@ -392,9 +392,15 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t hb = blockIdx.x * kTreeWaves + wv;
-    if (hb >= nhb_total) return;
-    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    // wave -> hzr block, plane-major: all the blocks of plane 0 (the dense, expensive ones) are dispatched first and
+    // next to each other, so they spread over every CU; in (b, k, j) order they recur with a period that the
+    // dispatcher's round-robin maps onto a quarter of the CUs (profiles/r01_notes.md: placement resonance)
+    const uint32_t v = blockIdx.x * kTreeWaves + wv;
+    if (v >= nhb_total) return;
+    const uint32_t per_plane = nhb_total / kMaxPlanes;  // = blocks * nblk
+    const uint32_t k = v / per_plane, rest = v - k * per_plane;
+    const uint32_t b = rest / g.nblk, j = rest - b * g.nblk;
+    const uint32_t hb = hb_index(g, b, k, j);
     TreeLds& t = s_t[wv];
     if (k >= nbuse[b]) {
         if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
