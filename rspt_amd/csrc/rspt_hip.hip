@@ -107,7 +107,7 @@ struct rspt_hip_packer {
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
-    uint32_t* work_ctr = nullptr;  // [1 + 4] work counter of the persistent k_hist, then the WorkQueues of k_encode (zeroed per call)
+    uint32_t* work_ctr = nullptr;  // [16] work counter of the persistent k_hist at 0, the WorkQueues of k_encode from 4 (zeroed per call)
     uint32_t* big_list = nullptr;  // [cap*4*nblk] hzr blocks for the workgroup-per-block encoder (filled by k_layout)
     uint32_t* small_list = nullptr;  // [cap*4*nblk] hzr blocks for the wave-per-block encoder
     int num_cu = 256;
@@ -533,7 +533,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
-    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 16) * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32) * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
@@ -582,7 +582,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
         p->needmask = p->nzflag + nhb_call;
         p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
-        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, (size_t)((p->work_ctr + 8) - p->nzflag) * sizeof(uint32_t), st));
+        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, (size_t)((p->work_ctr + 16) - p->nzflag) * sizeof(uint32_t), st));
     }
     uint32_t np = 4;
     switch (g.bps) {
