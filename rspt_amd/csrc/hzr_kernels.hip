@@ -70,14 +70,23 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
         const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
         const uint32_t trail = granule_trail_elem(g) & ~kZAll;
         const unsigned long long nonall = ~__ballot(allz);
-        const unsigned long long below = nonall & lt;
-        const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-        const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
-        fwd_incl[r] = below ? (16u * (l - 1u - p) + tp) : zcomb(carry, kZAll | (16u * l));
-        uint32_t rows = kZAll | 1024u;
-        if (nonall) {
-            const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
-            rows = 16u * (63u - ph) + read_lane(trail, ph);  // ph comes from a ballot: wave-uniform
+        uint32_t rows;
+        if (nonall == ~0ull) {
+            // dense row (no granule is all zero): the run before a lane ends in the lane below -- one DPP shift
+            // instead of the mask search and the bpermute
+            const uint32_t tp = dpp<0x138>(0u, trail);  // wave_shr:1
+            fwd_incl[r] = l ? tp : zcomb(carry, kZAll);
+            rows = read_lane(trail, 63);
+        } else {
+            const unsigned long long below = nonall & lt;
+            const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+            const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
+            fwd_incl[r] = below ? (16u * (l - 1u - p) + tp) : zcomb(carry, kZAll | (16u * l));
+            rows = kZAll | 1024u;
+            if (nonall) {
+                const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
+                rows = 16u * (63u - ph) + read_lane(trail, ph);  // ph comes from a ballot: wave-uniform
+            }
         }
         carry = zcomb(carry, rows);
     }
@@ -91,14 +100,21 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
         const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
         const uint32_t lead = granule_lead_elem(g) & ~kZAll;
         const unsigned long long nonall = ~__ballot(allz);
-        const unsigned long long above = nonall & gt;
-        const uint32_t q = above ? (uint32_t)__builtin_ctzll(above) : 63u;
-        const uint32_t lq = (uint32_t)__shfl((int)lead, (int)q, 64);
-        bwd_incl[r] = above ? (16u * (q - l - 1u) + lq) : zcomb(carry, kZAll | (16u * (63u - l)));
-        uint32_t rows = kZAll | 1024u;
-        if (nonall) {
-            const uint32_t ql = (uint32_t)__builtin_ctzll(nonall);
-            rows = 16u * ql + read_lane(lead, ql);
+        uint32_t rows;
+        if (nonall == ~0ull) {
+            const uint32_t lq = dpp<0x130>(0u, lead);  // wave_shl:1
+            bwd_incl[r] = l != 63u ? lq : zcomb(carry, kZAll);
+            rows = read_lane(lead, 0);
+        } else {
+            const unsigned long long above = nonall & gt;
+            const uint32_t q = above ? (uint32_t)__builtin_ctzll(above) : 63u;
+            const uint32_t lq = (uint32_t)__shfl((int)lead, (int)q, 64);
+            bwd_incl[r] = above ? (16u * (q - l - 1u) + lq) : zcomb(carry, kZAll | (16u * (63u - l)));
+            rows = kZAll | 1024u;
+            if (nonall) {
+                const uint32_t ql = (uint32_t)__builtin_ctzll(nonall);
+                rows = 16u * ql + read_lane(lead, ql);
+            }
         }
         carry = zcomb(carry, rows);
     }
