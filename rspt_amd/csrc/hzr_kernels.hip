@@ -142,6 +142,35 @@ __device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, u
     __syncthreads();  // scratch may be reused by the caller
 }
 
+// The same LaneBlock from memory: the granule words plus the (zb | za << 16) words k_hist stored for this
+// hzr block (`zbza` = [16 waves][4 rows][64 lanes]).  No ballots, shuffles or barriers.
+__device__ __forceinline__ void load_with_chain(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask,
+                                                const uint32_t* __restrict__ zbza, LaneBlock& L) {
+    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
+    const bool seg_nz = (segmask >> w) & 1u;
+    uint32_t zz[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) zz[r] = zbza[w * 256 + r * 64 + l];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = w * 4096 + r * 1024 + l * 16;
+        Granule& g = L.g[r];
+        g.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g.nv && seg_nz) v = *reinterpret_cast<const uint4*>(in + pos);
+        g.w[0] = v.x;
+        g.w[1] = v.y;
+        g.w[2] = v.z;
+        g.w[3] = v.w;
+        granule_finish(g);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        L.zb[r] = zz[r] & 0xFFFFu;
+        L.za[r] = zz[r] >> 16;
+    }
+}
+
 // byte i (dynamic) of a granule held in four registers
 __device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
     const uint32_t lo = (i & 8u) ? w2 : w0, hi = (i & 8u) ? w3 : w1;
@@ -233,7 +262,8 @@ constexpr uint32_t kSegHistStride = kEncWaves * kSymStride;  // u16 elements per
 
 __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
                                                      const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
-                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total) {
+                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ zbza, uint32_t* __restrict__ counter,
+                                                     uint32_t total) {
     __shared__ uint32_t s_hist[kEncWaves][kSymStride];
     __shared__ uint32_t s_scr[2 * kEncWaves];
     __shared__ uint32_t s_slot;
@@ -251,6 +281,12 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
         LaneBlock L;
         load_and_chain(in, in_size, segmask, L, s_scr);  // (its barriers also order the zeroing below against this block's adds)
+        {
+            // the zero-run context of every granule, for k_encode (which then needs no chaining of its own)
+            uint32_t* zo = zbza + (size_t)hb * kHzrBlock / 16 + (tid >> 6) * 256 + (tid & 63);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zo[r * 64] = L.zb[r] | (L.za[r] << 16);
+        }
         if (wave_may_have_tokens(segmask, L)) {
             uint32_t* myhist = s_hist[tid >> 6];
             GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
@@ -943,7 +979,8 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
                                              const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                              const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
                                              uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate_arg,
-                                             unsigned long long* __restrict__ stamps, const uint32_t* __restrict__ segbase) {
+                                             unsigned long long* __restrict__ stamps, const uint32_t* __restrict__ segbase,
+                                             const uint32_t* __restrict__ zbza) {
     EncLds& d = g_enc;
     const uint32_t ablate = DIAG ? ablate_arg : 0u;  // the production instantiation carries no diagnostic code
     // diagnostic (ablate bit 7): lane 0 of every wave of 512 hzr blocks (window ablate>>16) stores s_memtime at section seams
@@ -1003,7 +1040,12 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         LaneBlock B;
         const uint32_t first_base = segbase[(size_t)hb * kEncWaves];  // 0xFFFFFFFF: no offsets from k_tree (its own-histogram blocks)
         uint32_t base = segbase[(size_t)hb * kEncWaves + w];           // stream bit at which this wave's tokens start
-        load_and_chain(in, in_size, segmask, B, d.scr);  // barriers inside publish cw and the zeroed image
+        if (first_base == 0xFFFFFFFFu) {
+            load_and_chain(in, in_size, segmask, B, d.scr);  // barriers inside publish cw and the zeroed image
+        } else {
+            load_with_chain(in, in_size, segmask, zbza + (size_t)hb * kHzrBlock / 16, B);  // k_hist went through this block
+            __syncthreads();  // cw and the zeroed image are in place
+        }
         if (ablate & 32u) return;
         RSPT_STAMP(1);
         const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
@@ -1348,7 +1390,8 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
                                                           const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                           uint32_t ablate, unsigned long long* __restrict__ stamps, WorkQueues* __restrict__ wq,
-                                                          const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase) {
+                                                          const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase,
+                                                          const uint32_t* __restrict__ zbza) {
     __shared__ uint32_t s_slot;
     (&g_enc.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_enc.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
@@ -1363,7 +1406,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
         if (i >= n_big) break;
         const uint32_t hb = big_list[i];
         const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
-        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps, segbase);
+        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps, segbase, zbza);
     }
 }
 

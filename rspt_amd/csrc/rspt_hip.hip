@@ -115,6 +115,7 @@ struct rspt_hip_packer {
     uint32_t* nb_state = nullptr;  // [1] persistent
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
     uint32_t* seghist = nullptr;   // [cap*4*nblk][16][264] u16: tokens starting in each 4 KiB segment (k_hist -> k_tree)
+    uint32_t* zbza = nullptr;      // [cap*4*nblk][4096] zeros before | after << 16 of every 16-byte granule (k_hist -> k_encode)
     uint32_t* segbase = nullptr;   // [cap*4*nblk][16] stream bit at which each segment's tokens start (k_tree -> k_encode)
     uint32_t* cw = nullptr;        // same
     uint32_t* tdesc = nullptr;     // [..][92]
@@ -272,7 +273,8 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->hist);
     hipFree(p->seghist);
     hipFree(p->segbase);
-    p->seghist = p->segbase = nullptr;
+    hipFree(p->zbza);
+    p->seghist = p->segbase = p->zbza = nullptr;
     hipFree(p->cw);
     hipFree(p->tdesc);
     hipFree(p->meta);
@@ -540,6 +542,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->cw, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->seghist, nhb * (size_t)kSegHistStride * sizeof(uint16_t)) == hipSuccess;
     ok &= hipMalloc(&p->segbase, nhb * (size_t)kEncWaves * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->zbza, nhb * (size_t)(kHzrBlock / 16) * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->tdesc, nhb * kTdescWords * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->meta, nhb * sizeof(BlockMeta)) == hipSuccess;
     ok &= hipMalloc(&p->out_off, nhb * sizeof(uint64_t)) == hipSuccess;
@@ -623,7 +626,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_HIST, st);
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
     const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
-    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->work_ctr, nhb);
+    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->zbza, p->work_ctr, nhb);
 
     stamp(p, ST_TREE, st);
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
@@ -647,10 +650,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     }
     if (p->ablate)
         hipLaunchKernelGGL((k_encode<true>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
-                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, wq, p->big_list, p->segbase);
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, p->ablate, p->stamps, wq, p->big_list, p->segbase, p->zbza);
     else
         hipLaunchKernelGGL((k_encode<false>), dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
-                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, 0u, p->stamps, wq, p->big_list, p->segbase);
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, 0u, p->stamps, wq, p->big_list, p->segbase, p->zbza);
     stamp(p, ST_ENCODE_SMALL, st);
     HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
