@@ -850,12 +850,55 @@ __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t
 //           with extra bits, or a pair of codes longer than 32 bits (both rare in dense planes), is counted
 //           here and emitted token by token afterwards.
 constexpr int kRowSlots = 8;
+constexpr uint32_t kTokQueue = 256;          // tokens per wave and row in the queue of a light block
+constexpr uint32_t kLightPayload = 16384;    // bytes: below it the image words from kTokQueueBase on are free
+constexpr uint32_t kTokQueueBase = 9000;     // physical stage word (> skew((16384 + 4) / 4 + 24))
 
 __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
-                                         const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t* stage, uint32_t& base) {
+                                         const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t* stage, uint32_t& base, uint32_t* tokq) {
     const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t tokmask = m.single | m.runs;
     if (!__ballot(tokmask != 0)) return;  // no token starts in this row
+
+    if (tokq) {
+        // Light block (the image beyond its short payload serves as a token queue): a sparse row's tokens sit unevenly
+        // on the lanes (1.4 per lane on average, 6..8 on the fullest), so the lanes only QUEUE them, in stream order,
+        // and the wave then encodes the queue 64 tokens at a time, one token per lane.
+        const uint32_t n = (uint32_t)__popc(tokmask);
+        const uint32_t incl = wave_scan_add(n);
+        const uint32_t T = read_lane(incl, 63);
+        if (T <= kTokQueue) {
+            uint32_t k = incl - n, t = tokmask;
+            while (t) {
+                const uint32_t i = (uint32_t)__builtin_ctz(t);
+                t &= t - 1;
+                const uint32_t z = run_token_length(zm, nv, za, i);
+                const uint32_t lit = granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8);
+                tokq[k++] = ((m.runs >> i) & 1u) ? (0x80000000u | z) : lit;  // run: its length; else the lookup index
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t l = lane_id();
+            for (uint32_t c = 0; c < T; c += 64) {
+                const bool valid = c + l < T;
+                const uint32_t dsc = valid ? tokq[c + l] : 0u;
+                const bool is_run = dsc >> 31;
+                const uint32_t z = dsc & 0x7FFFFFFFu;
+                const uint32_t e = s_runcls[min(z, kRunClsEntries - 1u)];
+                const uint32_t cr = s_cw[is_run ? (e & 0xFFFu) : (dsc & 0x1FFu)];
+                const uint32_t cl = cr >> 24;
+                const uint32_t xv = is_run ? z - (e >> 16) : 0u;
+                const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)xv << cl);
+                const uint32_t len = valid ? cl + (is_run ? ((e >> 12) & 0xFu) : 0u) : 0u;
+                const uint32_t inc = wave_scan_add(len);
+                const uint32_t pos = base + inc - len;
+                base += read_lane(inc, 63);
+                if (len) or_token(stage, pos, (uint32_t)v, (uint32_t)(v >> 32), len);
+            }
+            __builtin_amdgcn_wave_barrier();  // the queue is reused by the next row
+            return;
+        }
+    }
 
     if (!__ballot(__popc(tokmask) > kRowSlots)) {
         uint32_t tlo[kRowSlots], thi[kRowSlots], tlen[kRowSlots];
@@ -1073,9 +1116,12 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         }
         RSPT_STAMP(2);
         RSPT_STAMP(3);
+        uint32_t* tokq = L < kLightPayload ? d.stage + kTokQueueBase + w * kTokQueue : nullptr;
+        // (diagnostic bits 18 / 19: no row emission for heavy / light blocks, to split the instruction count between them)
+        const bool skip_rows = (ablate & 1u) || ((ablate & (1u << 18)) && m.payload_len >= 16384u) || ((ablate & (1u << 19)) && m.payload_len < 16384u);
 #pragma unroll 1
-        for (int r = 0; r < 4 && active && !(ablate & 1u); ++r) {
-            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.runcls, d.stage, base);
+        for (int r = 0; r < 4 && active && !skip_rows; ++r) {
+            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.runcls, d.stage, base, tokq);
             q0 = q1;
             q1 = q2;
             q2 = q3;
