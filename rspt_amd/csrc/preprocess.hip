@@ -129,6 +129,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     // the next item's loads are issued before the current item is transformed: the HBM round trip hides behind
     // ~250 VALU instructions instead of stalling the wave (8 waves per CU cannot hide it by themselves)
     ItemRegs cur, nxt;
+    uint32_t nz_seg = 0xFFFFFFFFu, nz_done = 0;  // segment (flat index >> 12) this thread is in, planes already flagged for it
     uint32_t q = tid;
     bool have = q < nitems;
     if (have) load_item(q, cur);
@@ -202,27 +203,32 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
                 *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
             nzm |= ((pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0 ? 1u : 0u) << k;
         }
-        if (!fixup && !(ablate & 65536u) && nzm) {
+        // Non-zero map.  A thread mostly walks along one channel, and a tile row spans at most two 4 KiB segments: the
+        // bits this thread has already forwarded for the segment it is in live in a register, so the common item costs
+        // a compare and no LDS round trip.
+        if (!fixup && !(ablate & 65536u)) {
             const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
-            const uint32_t jb = (c * g.ns + s0) >> 16;
-            const uint32_t ja = f0 >> 16, jz = f1 >> 16;
-            const uint32_t ba = 1u << ((f0 >> 12) & 15u), bz = 1u << ((f1 >> 12) & 15u);
-            const bool two = jz != ja || bz != ba;  // (an item straddling a segment edge marks both sides: conservative)
-            uint32_t* za = &s_nz[((ja - jb) * 4) * g.nch + c];
-            uint32_t* zz = &s_nz[((jz - jb) * 4) * g.nch + c];
-            // plain reads first (the four of them in one wait): the atomics are needed once per (plane, channel, segment) and tile
-            uint32_t have_a[4], have_z[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                have_a[k] = za[k * g.nch];
-                have_z[k] = two ? zz[k * g.nch] : bz;
+            const uint32_t seg = f0 >> 12;
+            if (seg != nz_seg) {
+                nz_seg = seg;
+                nz_done = 0;
             }
+            const bool two = (f1 >> 12) != seg;  // (an item straddling a segment edge marks both sides: conservative)
+            const uint32_t need = two ? nzm : (nzm & ~nz_done);
+            nz_done |= nzm;
+            if (need) {
+                const uint32_t jb = (c * g.ns + s0) >> 16;
+                const uint32_t ja = f0 >> 16, jz = f1 >> 16;
+                const uint32_t ba = 1u << (seg & 15u), bz = 1u << ((f1 >> 12) & 15u);
+                uint32_t* za = &s_nz[((ja - jb) * 4) * g.nch + c];
+                uint32_t* zz = &s_nz[((jz - jb) * 4) * g.nch + c];
 #pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if (!((nzm >> k) & 1u)) continue;
-                // (fire-and-forget global atomics: the first setter in the workgroup forwards the bit to HBM)
-                if (!(have_a[k] & ba) && !(atomicOr(&za[k * g.nch], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
-                if (two && !(have_z[k] & bz) && !(atomicOr(&zz[k * g.nch], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (!((need >> k) & 1u)) continue;
+                    // the first setter in the workgroup forwards the bit to HBM (fire-and-forget)
+                    if (!(atomicOr(&za[k * g.nch], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
+                    if (two && !(atomicOr(&zz[k * g.nch], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
+                }
             }
         }
         cur = nxt;
