@@ -344,18 +344,19 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         p->T = (uint32_t)(t > 4096 ? 4096 : t);
         if (p->T > ns16) p->T = ns16;
         p->in_lds = (uint32_t)(((uint64_t)p->T * rowb + 16 + 15) & ~15ull);
-        // k_tile_planes keeps only the plane rows in LDS: kcount*nch*(Tp+16) + 32*nch bytes, <= 72 KiB
+        // k_tile_planes keeps only the plane rows in LDS: kcount*nch*(Tp+16) + 32*nch bytes, <= 79 KiB
         // (two workgroups per CU).  Long row segments matter more than occupancy here: 256-byte plane
-        // rows beat 64-byte ones by 2.5x (profiles/r01_tile_sweep.txt).
+        // rows beat 64-byte ones by 2.5x (profiles/r01_tile_sweep.txt); segments that are whole 128-byte
+        // lines beat ragged ones of about the same length (384 vs 352: -4 %).
         for (uint32_t kc = 1; kc <= 4; ++kc) {
             auto fit = [&](uint64_t budget) -> uint32_t {
                 const uint64_t fixed = (16ull * kc + 32ull) * g.nch;
                 if (budget <= fixed) return 0;
                 uint64_t tt = (budget - fixed) / ((uint64_t)kc * g.nch);
-                tt &= ~15ull;
+                tt &= tt >= 256 ? ~127ull : ~15ull;
                 return (uint32_t)(tt > 2048 ? 2048 : tt);
             };
-            uint32_t Tp = fit(72 * 1024);
+            uint32_t Tp = fit(79 * 1024);
             if (Tp < 16) Tp = fit(150 * 1024);
             if (const char* e = getenv("RSPT_TILE")) Tp = (uint32_t)atoi(e) & ~15u;  // tuning knob
             if (Tp < 16) {
