@@ -49,6 +49,42 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
     return sample_from_bytes<BPS>(blk + ((size_t)s * g.nch + c) * BPS, false);
 }
 
+// an item's 18 samples (16 + the two before them, for the delta and the xor) in registers
+struct ItemRegs {
+    uint32_t pv[16];
+    uint32_t p1, p2;
+};
+
+// item q (channel q % nch, samples [s0 + 16 (q / nch), +16)) of the tile [s0, s0 + Tn) of block `blk`
+template <int BPS, bool XDELTA>
+__device__ __forceinline__ void load_item(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t Tn, bool aligned4,
+                                          uint32_t ablate, uint32_t q, ItemRegs& R) {
+    const size_t rstride = (size_t)g.nch * BPS;
+    const uint32_t grp = fast_div(q, g.nch, m_nch);
+    const uint32_t c = q - grp * g.nch;
+    const uint32_t t0 = grp << 4;
+    const uint32_t cnt = min(16u, Tn - t0);
+    const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
+    if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+    }
+    R.p1 = R.p2 = 0;
+    if (XDELTA) {
+        if (s0 + t0 >= 2) {  // same channel, two samples back
+            R.p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
+            R.p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
+        } else {  // channel start: the flat array continues from the end of channel c-1
+            const int64_t flat = (int64_t)c * g.ns + s0 + t0;
+            R.p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
+            R.p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
+        }
+    }
+}
+
 // One workgroup = one tile of T samples x all channels of one block.
 //   XDELTA  true : v = (p[i]-p[i-1]-128) ^ (p[i-1]-p[i-2]-128), flat order; accumulates needmask
 //           false: v = p (hzr packer)
@@ -72,10 +108,27 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     const bool fixup = nbuse != nullptr;
     const uint32_t tiles_per_block = (g.ns + T - 1) / T;
     // persistent: the grid is a few workgroups per CU, each walks tiles with a fixed stride
-    for (uint32_t work = blockIdx.x; work < tiles_per_block * nblocks; work += gridDim.x) {
+    const uint32_t total = tiles_per_block * nblocks;
+    const uint32_t m_nch = magic_of(g.nch);
+    // (the fix-up pass touches only the blocks whose nb grew past kfirst)
+    auto skip_untouched = [&](uint32_t wk) {
+        while (wk < total && fixup && nbuse[wk / tiles_per_block] <= kfirst) wk += gridDim.x;
+        return wk;
+    };
+    auto tile_s0 = [&](uint32_t wk) { return (wk - (wk / tiles_per_block) * tiles_per_block) * T; };
+    uint32_t work = skip_untouched(blockIdx.x);
+    // The first item of a tile is loaded before the previous tile's rows are stored: vmcnt retires in issue order, so a
+    // load issued behind 18 KiB of stores would wait for their write acknowledgements before the tile could start.
+    ItemRegs cur, nxt;
+    if (work < total) {
+        const uint32_t s0f = tile_s0(work), Tnf = min(T, g.ns - s0f);
+        const uint8_t* blkf = src + (size_t)(work / tiles_per_block) * g.block_bytes;
+        if (tid < g.nch * ((Tnf + 15) >> 4))
+            load_item<BPS, XDELTA>(blkf, g, m_nch, s0f, Tnf, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkf) & 3u) == 0), ablate, tid, cur);
+    }
+    while (work < total) {
     const uint32_t b = work / tiles_per_block;
-    if (fixup && nbuse[b] <= kfirst) continue;
-    const uint32_t s0 = (work - b * tiles_per_block) * T;
+    const uint32_t s0 = tile_s0(work);
     __syncthreads();  // the previous tile's rows have left LDS
     const uint32_t Tn = min(T, g.ns - s0);
     const uint8_t* blk = src + (size_t)b * g.block_bytes;
@@ -93,50 +146,16 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     // ---- per (channel, 16-sample group): load, transform, plane split ---------
     const uint32_t ngrp = (Tn + 15) >> 4;
     const uint32_t nitems = g.nch * ngrp;
-    const uint32_t m_nch = magic_of(g.nch);
     uint32_t mag = 0;
-    const size_t rstride = (size_t)g.nch * BPS;
-    // an item's 18 samples (16 + the two before them, for the delta and the xor) in registers
-    struct ItemRegs {
-        uint32_t pv[16];
-        uint32_t p1, p2;
-    };
-    auto load_item = [&](uint32_t q, ItemRegs& R) {
-        const uint32_t grp = fast_div(q, g.nch, m_nch);
-        const uint32_t c = q - grp * g.nch;
-        const uint32_t t0 = grp << 4;
-        const uint32_t cnt = min(16u, Tn - t0);
-        const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
-        if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
-#pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
-        } else {
-#pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
-        }
-        R.p1 = R.p2 = 0;
-        if (XDELTA) {
-            if (s0 + t0 >= 2) {  // same channel, two samples back
-                R.p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
-                R.p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
-            } else {  // channel start: the flat array continues from the end of channel c-1
-                const int64_t flat = (int64_t)c * g.ns + s0 + t0;
-                R.p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
-                R.p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
-            }
-        }
-    };
     // the next item's loads are issued before the current item is transformed: the HBM round trip hides behind
     // ~250 VALU instructions instead of stalling the wave (8 waves per CU cannot hide it by themselves)
-    ItemRegs cur, nxt;
     uint32_t nz_seg = 0xFFFFFFFFu, nz_done = 0;  // segment (flat index >> 12) this thread is in, planes already flagged for it
     uint32_t q = tid;
-    bool have = q < nitems;
-    if (have) load_item(q, cur);
+    bool have = q < nitems;  // (item `tid` is in `cur` already)
     while (have) {
         const uint32_t qn = q + nthr;
         const bool have_next = qn < nitems;
-        if (have_next) load_item(qn, nxt);
+        if (have_next) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, qn, nxt);
         const uint32_t grp = fast_div(q, g.nch, m_nch);
         const uint32_t c = q - grp * g.nch;
         const uint32_t t0 = grp << 4;
@@ -235,6 +254,13 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         q = qn;
         have = have_next;
     }
+    const uint32_t work_next = skip_untouched(work + gridDim.x);
+    if (work_next < total) {
+        const uint32_t s0n = tile_s0(work_next), Tnn = min(T, g.ns - s0n);
+        const uint8_t* blkn = src + (size_t)(work_next / tiles_per_block) * g.block_bytes;
+        if (tid < g.nch * ((Tnn + 15) >> 4))
+            load_item<BPS, XDELTA>(blkn, g, m_nch, s0n, Tnn, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkn) & 3u) == 0), ablate, tid, cur);
+    }
     if (XDELTA && !fixup) {
         // only the three thresholds matter (need_from_mask): fold to the top bit of each byte range, and
         // skip the same-address atomic when the block's mask already has it (750 tiles x waves per block)
@@ -265,6 +291,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
             for (uint32_t i = 0; i < nbytes; ++i) dp[i] = sp[i];
         }
     }
+    work = work_next;
     }  // tile loop
 }
 
