@@ -200,13 +200,32 @@ def main():
     in_bytes = B * pk.block_bytes
     samples_per_step = B * nch * ns
 
+    # second denominator: what a plain device copy reaches on this very GPU (bytes read + bytes written)
+    copy_gbs = None
+    try:
+        a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        c = torch.empty_like(a)
+        c.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            c.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * a.numel() * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, c
+    except Exception:
+        copy_gbs = None
+
     if rank == 0:
         dominant = max(acc, key=acc.get)
         alg_bytes = in_bytes + out_bytes  # bytes = input_bytes + output_bytes per launch
         achieved = alg_bytes / (acc[dominant] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        default_shape = (args.packer, B, nch, ns, args.nb) == ("xdelta_hzr", 64, 64, 65536, 3)  # what the counters were collected on
+        if default_shape and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dominant)
             except Exception:
@@ -244,6 +263,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                 "pipeline_frac": round(alg_bytes / (sum(acc.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "device_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
             },
         }
         if world == 1 and not args.no_cpu:
