@@ -423,7 +423,11 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         return RSPT_HIP_ERR_LAUNCH;
     }
     for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&p->ev[i]);
-    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess ||
+    // (highest priority: the latency-bound small blocks go first and are done long before the big encoder, so that the
+    // join at the end of the call finds its event complete)
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&p->side, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
         rspt_hip_packer_destroy(p);
