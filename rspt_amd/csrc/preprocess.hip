@@ -49,6 +49,38 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
     return sample_from_bytes<BPS>(blk + ((size_t)s * g.nch + c) * BPS, false);
 }
 
+__device__ __forceinline__ uint32_t need_from_mask(uint32_t m) { return m < 0x80u ? 1u : m < 0x8000u ? 2u : m < 0x800000u ? 3u : 4u; }
+
+// nbuse[b] = max(nb carried in, need(0..b)); the last value is carried to the next call (the reference's persistent
+// escalation, signal_packer_xdelta_hzr.cpp:63-69).  One workgroup of any size; `wmax` = 16 words of LDS.
+// needmask is read past the vector L1 (agent scope): its bits were set by other workgroups of the running kernel.
+__device__ __forceinline__ void nb_scan_body(const uint32_t* __restrict__ needmask, uint32_t nblocks, uint32_t* __restrict__ nb_state,
+                                             uint32_t* __restrict__ nbuse, int use_mask, uint32_t* wmax) {
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const uint32_t per = (nblocks + nthr - 1) / nthr;
+    const uint32_t lo = min(nblocks, tid * per), hi = min(nblocks, lo + per);
+    const uint32_t carry_in = *nb_state;
+    auto need = [&](uint32_t b) -> uint32_t {
+        return use_mask ? need_from_mask(__hip_atomic_load(&needmask[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0u;
+    };
+    uint32_t m = 0;
+    for (uint32_t b = lo; b < hi; ++b) m = max(m, need(b));
+    const uint32_t l = lane_id(), w = tid >> 6;
+    const uint32_t v = wave_scan_incl(m, 0u, [](uint32_t a, uint32_t c) { return a > c ? a : c; });  // inclusive max-scan over the wave
+    if (l == 63) wmax[w] = v;
+    __syncthreads();
+    uint32_t pre = carry_in;
+    for (uint32_t i = 0; i < w; ++i) pre = max(pre, wmax[i]);
+    const uint32_t excl = dpp<0x138>(0u, v);  // wave_shr:1
+    uint32_t run = max(pre, l ? excl : 0u);
+    for (uint32_t b = lo; b < hi; ++b) {
+        run = max(run, need(b));
+        nbuse[b] = run;
+    }
+    __syncthreads();
+    if (tid == nthr - 1) *nb_state = max(pre, v);
+}
+
 // an item's 18 samples (16 + the two before them, for the delta and the xor) in registers
 struct ItemRegs {
     uint32_t pv[16];
@@ -102,7 +134,8 @@ template <int BPS, bool XDELTA>
 __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                      uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
                                                      uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
-                                                     uint32_t nblocks) {
+                                                     uint32_t nblocks, uint32_t* __restrict__ ticket, uint32_t* __restrict__ nb_state,
+                                                     uint32_t* __restrict__ nbuse_out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const bool fixup = nbuse != nullptr;
@@ -293,6 +326,20 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     }
     work = work_next;
     }  // tile loop
+    // main pass: the last workgroup to get here runs the escalation scan over the blocks (saves a launch and its gap)
+    if (ticket) {
+        __shared__ uint32_t s_last, s_wmax[16];
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();  // this workgroup's needmask atomics are out
+            s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            nb_scan_body(needmask, nblocks, nb_state, nbuse_out, XDELTA ? 1 : 0, s_wmax);
+        }
+    }
 }
 
 // planar int32 [nch][ns] (the output of a transform kernel) -> planes, with the
@@ -375,47 +422,17 @@ __global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__
 // nb bookkeeping (signal_packer_xdelta_hzr.cpp:63-69): nb used by block b =
 // max(nb carried in, need(0..b)); the last value is carried to the next call.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t need_from_mask(uint32_t m) { return m < 0x80u ? 1u : m < 0x8000u ? 2u : m < 0x800000u ? 3u : 4u; }
-
-// single workgroup of 1024 threads; nblocks arbitrary
+// single workgroup; nblocks arbitrary (the xdelta / hzr front ends run the same scan in their last workgroup)
 __global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ needmask, uint32_t nblocks, uint32_t* __restrict__ nb_state,
                                                   uint32_t* __restrict__ nbuse, int use_mask) {
     __shared__ uint32_t wmax[16];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (nblocks + 1023) / 1024;
-    const uint32_t lo = tid * per, hi = min(nblocks, lo + per);
-    const uint32_t carry_in = *nb_state;
-    uint32_t m = 0;
-    for (uint32_t b = lo; b < hi; ++b) m = max(m, use_mask ? need_from_mask(needmask[b]) : 0u);
-    // inclusive max-scan over threads
-    uint32_t v = m;
-    const uint32_t l = lane_id(), w = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-        if (l >= (uint32_t)d) v = max(v, o);
-    }
-    if (l == 63) wmax[w] = v;
-    __syncthreads();
-    uint32_t pre = carry_in;
-    for (uint32_t i = 0; i < w; ++i) pre = max(pre, wmax[i]);
-    uint32_t excl = (uint32_t)__shfl_up((int)v, 1, 64);
-    uint32_t run = max(pre, l ? excl : 0u);
-    for (uint32_t b = lo; b < hi; ++b) {
-        run = max(run, use_mask ? need_from_mask(needmask[b]) : 0u);
-        nbuse[b] = run;
-    }
-    __syncthreads();
-    if (tid == 1023) {
-        uint32_t fin = max(pre, v);
-        *nb_state = fin;
-    }
+    nb_scan_body(needmask, nblocks, nb_state, nbuse, use_mask, wmax);
 }
 
 // explicit instantiations used by rspt_hip.cpp
 #define INST_TILE(BPS)                                                                                                   \
-    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t);    \
-    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t);   \
+    template __global__ void k_tile_planes<BPS, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);    \
+    template __global__ void k_tile_planes<BPS, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);   \
     template __global__ void k_tile_planar<BPS>(const uint8_t*, Geom, uint32_t, int32_t*);
 INST_TILE(1)
 INST_TILE(2)

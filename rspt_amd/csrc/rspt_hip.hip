@@ -192,7 +192,8 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     if (const char* e = getenv("RSPT_K1_GRID")) want = (uint32_t)atoi(e);
     dim3 grid(want < ntiles ? want : ntiles);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(p->k1_threads), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate, (uint32_t)nblocks);
+    hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(p->k1_threads), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate, (uint32_t)nblocks,
+                       nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse);
 }
 
 // main front-end pass; returns the number of planes it wrote (xdelta: nb as last seen by the host)
@@ -618,7 +619,8 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     HIPCHK(p, hipGetLastError());
 
     stamp(p, ST_NB, st);
-    hipLaunchKernelGGL(k_nb_scan, dim3(1), dim3(1024), 0, st, p->needmask, B, p->nb_state, p->nbuse, xd ? 1 : 0);
+    if (g.kind != RSPT_HIP_KIND_XDELTA_HZR && g.kind != RSPT_HIP_KIND_HZR)  // (k_tile_planes runs the scan in its last workgroup)
+        hipLaunchKernelGGL(k_nb_scan, dim3(1), dim3(1024), 0, st, p->needmask, B, p->nb_state, p->nbuse, 0);
     if (xd && np < 4) {  // nb may have escalated in this call: add the planes the main pass did not write
         switch (g.bps) {
             case 1: launch_fixup<1>(p, src, nblocks, np, st); break;
