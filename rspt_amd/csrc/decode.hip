@@ -78,10 +78,21 @@ __global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride
 }
 
 // ---------------------------------------------------------------------------
-// k_dec_block
+// k_dec_block: one 1024-thread workgroup per hzr block.
+//
+// A Huffman stream has no index, but a decoder that starts at a wrong bit falls into step with the right one after a
+// few symbols.  So the code bits are cut into up to 1024 chunks and every thread decodes one:
+//   pass 0     from the chunk's nominal first bit (only chunk 0's is certain) to the first code boundary past its end
+//   pass 1..   a chunk whose predecessor ended somewhere else than where it started decodes again from there; the first
+//              wrong chunk always becomes right, so the loop ends (typically after 2-3 rounds, at worst one per chunk)
+//   final      prefix sum of the bytes each chunk produces, then every chunk decodes once more and writes its literals
+//              (the output is zeroed first: zero runs are skips)
+// Speculative rounds meet garbage by design: they never report errors, they only stop at the end of the payload.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kLutBits = 10;
 constexpr uint32_t kLutSlow = 0xFFFFFFFFu;
+constexpr uint32_t kDecThreads = 1024;
+constexpr uint32_t kDecMinChunkBits = 256;
 
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
@@ -92,8 +103,11 @@ struct DecLds {
     uint16_t leaf_meta[kSymStride];  // sym | len<<9
     uint16_t stack[64][2];           // (node, depth) -- codes travel in a parallel array
     uint32_t stack_code[64];
+    uint32_t cstart[kDecThreads], cend[kDecThreads];  // first bit a chunk decodes from / first code boundary past its end
+    uint32_t wsum[kDecThreads / 64];
     uint32_t nleaf;
     uint32_t err;
+    uint32_t changed;
 };
 
 // 32 stream bits starting at absolute bit position `bp` of the LDS image
@@ -103,12 +117,63 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
     return (uint32_t)(v >> sh);
 }
 
-__global__ __launch_bounds__(64) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g, const uint32_t* __restrict__ nb_state,
-                                                 const uint64_t* __restrict__ blk_off, uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed) {
+// Decode from bit `bp` until a code boundary >= `limit` (or the end of the payload).  Returns that boundary; `produced`
+// = output bytes of the tokens decoded.  WRITE: literals go to out[o0...] (bounded by out_size).
+// max_out: stop as soon as that many output bytes are produced (the last chunk: the final byte's pad bits are not codes).
+template <bool WRITE>
+__device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint32_t limit, uint32_t bit_end, uint32_t& produced, uint8_t* out,
+                                              uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
+    uint32_t o = o0;
+    while (bp < limit && o - o0 < max_out) {
+        const uint32_t bits = peek32(d.stage, bp);
+        const uint32_t e = d.lut[bits & ((1u << kLutBits) - 1u)];
+        uint32_t sym, len;
+        if (e != kLutSlow) {
+            sym = e & 511u;
+            len = e >> 9;
+        } else {
+            uint32_t nd = 0;
+            len = 0;
+            while (d.nsym[nd] < 0 && len < 32) {
+                nd = d.child[nd][(bits >> len) & 1u];
+                ++len;
+            }
+            if (d.nsym[nd] < 0) {  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
+                err = 1;
+                break;
+            }
+            if (len == 0) len = 1;  // single-leaf tree: one bit per symbol (hzr_decode.c:463-470)
+            sym = (uint32_t)d.nsym[nd];
+        }
+        bp += len;
+        if (sym < 256) {
+            if (WRITE && sym && o < out_size) out[o] = (uint8_t)sym;
+            ++o;
+        } else {
+            const uint32_t eb = run_extra_bits(sym);
+            uint32_t z = sym == 256 ? 2u : sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : 279u;
+            if (eb) {
+                z += peek32(d.stage, bp) & ((1u << eb) - 1u);
+                bp += eb;
+            }
+            o += z;
+        }
+        if (bp > bit_end) {  // ran over the payload
+            err = 1;
+            break;
+        }
+    }
+    produced = o - o0;
+    return bp;
+}
+
+__global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
+                                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
+                                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed) {
     __shared__ DecLds d;
-    const uint32_t k = blockIdx.x, j = blockIdx.y, b = blockIdx.z;  // plane fastest: see k_encode
+    const uint32_t k = blockIdx.x, j = blockIdx.y, b = blockIdx.z;
     if (k >= *nb_state) return;
-    const uint32_t l = threadIdx.x;
+    const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint32_t hb = hb_index(g, b, k, j);
     const uint64_t off = blk_off[hb];
     if (off == ~0ull) return;
@@ -120,40 +185,40 @@ __global__ __launch_bounds__(64) void k_dec_block(const uint8_t* __restrict__ sr
 
     if (mode == kModeFill) {  // hzr_decode.c:362-370
         const uint32_t v = s[7] * 0x01010101u;
-        for (uint32_t i = l; i < (out_size + 15) / 16; i += 64) reinterpret_cast<uint4*>(out)[i] = make_uint4(v, v, v, v);  // rows are padded
+        for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(v, v, v, v);  // rows are padded
         return;
     }
     // stage the payload with 16-byte aligned global loads
     const uint8_t* pay = s + 7;
     const uint32_t skew = (uint32_t)(reinterpret_cast<uintptr_t>(pay) & 15u);
     const uint8_t* abase = pay - skew;
-    for (uint32_t o = l * 16; o < skew + L; o += 64 * 16) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    const uint8_t* st8 = reinterpret_cast<const uint8_t*>(d.stage) + skew;
+    for (uint32_t o = tid * 16; o < skew + L; o += kDecThreads * 16)
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
+    if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // peek32 reads one word past the last payload word
+    __syncthreads();
 
     if (mode == kModeCopy) {  // hzr_decode.c:351-359
         if (L != out_size) {
-            if (l == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+            if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
             return;
         }
-        for (uint32_t i = l; i < (out_size + 15) / 16; i += 64) {
-            uint32_t w[4];
+        for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) {
+            uint32_t wq[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t a = skew + i * 16 + q * 4;
-                w[q] = __builtin_amdgcn_alignbyte(d.stage[(a >> 2) + 1], d.stage[a >> 2], a & 3u);
+                wq[q] = __builtin_amdgcn_alignbyte(d.stage[(a >> 2) + 1], d.stage[a >> 2], a & 3u);
             }
-            reinterpret_cast<uint4*>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<uint4*>(out)[i] = make_uint4(wq[0], wq[1], wq[2], wq[3]);
         }
         return;
     }
 
     // ---- Huffman + RLE -------------------------------------------------------
-    for (uint32_t i = l; i < (out_size + 15) / 16; i += 64) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);  // zero runs = untouched bytes
-    for (uint32_t i = l; i < (1u << kLutBits); i += 64) d.lut[i] = kLutSlow;
+    for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);  // zero runs = untouched bytes
+    for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;
     const uint32_t bit0 = skew * 8, bit_end = (skew + L) * 8;
-    if (l == 0) {
+    if (tid == 0) {
         // RecoverTree (hzr_decode.c:263-333), iteratively, pre-order: child_a first
         uint32_t bp = bit0, nn = 1, sp = 0, nleaf = 0, err = 0;
         d.stack[0][0] = 0;
@@ -204,68 +269,72 @@ __global__ __launch_bounds__(64) void k_dec_block(const uint8_t* __restrict__ sr
         d.err = err;
         d.stack_code[63] = bp;  // where the codes start
     }
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     if (d.err) {
-        if (l == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+        if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
     // LUT: every leaf with len <= 10 owns the entries code + m*2^len (code bits are LSB-first, root decision = bit 0)
     const uint32_t nleaf = d.nleaf;
-    for (uint32_t i = l; i < nleaf; i += 64) {
+    for (uint32_t i = tid; i < nleaf; i += kDecThreads) {
         const uint32_t meta = d.leaf_meta[i], len = meta >> 9, code = d.leaf_code[i];
         // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
         const uint32_t elen = len ? len : 1u;
         if (elen <= kLutBits)
             for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = (meta & 511u) | (elen << 9);
     }
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t code0 = d.stack_code[63];
+    __syncthreads();
 
-    if (l == 0) {
-        uint32_t bp = d.stack_code[63], o = 0, err = 0;
-        while (o < out_size) {
-            if (bp >= bit_end) {
-                err = 1;
-                break;
-            }
-            const uint32_t bits = peek32(d.stage, bp);
-            uint32_t e = d.lut[bits & ((1u << kLutBits) - 1u)], sym, len;
-            if (e != kLutSlow) {
-                sym = e & 511u;
-                len = e >> 9;
-            } else {
-                uint32_t nd = 0;
-                len = 0;
-                while (d.nsym[nd] < 0 && len < 32) {
-                    nd = d.child[nd][(bits >> len) & 1u];
-                    ++len;
-                }
-                if (d.nsym[nd] < 0) {
-                    err = 1;
-                    break;
-                }
-                if (len == 0) len = 1;  // single-leaf tree: one bit per symbol (hzr_decode.c:463-470)
-                sym = (uint32_t)d.nsym[nd];
-            }
-            bp += len;
-            if (sym < 256) {
-                if (sym) out[o] = (uint8_t)sym;
-                ++o;
-            } else {
-                const uint32_t eb = run_extra_bits(sym);
-                const uint32_t base = sym == 256 ? 2u : sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : 279u;
-                uint32_t z = base;
-                if (eb) {
-                    z += peek32(d.stage, bp) & ((1u << eb) - 1u);
-                    bp += eb;
-                }
-                o += z;
-            }
-        }
-        if (o != out_size || bp > bit_end) err = 1;
-        if (err) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+    // ---- chunks ---------------------------------------------------------------
+    const uint32_t nbits = bit_end - code0;
+    uint32_t nchunk = (nbits + kDecMinChunkBits - 1) / kDecMinChunkBits;
+    nchunk = nchunk < 1 ? 1u : nchunk > kDecThreads ? kDecThreads : nchunk;
+    const uint32_t S = (nbits + nchunk - 1) / nchunk;  // bits per chunk
+    const bool mine = tid < nchunk;
+    const uint32_t limit = tid + 1 == nchunk ? bit_end : min(bit_end, code0 + (tid + 1) * S);
+    uint32_t start = code0 + tid * S, produced = 0, spec_err = 0;
+    if (mine) {
+        d.cstart[tid] = start;
+        d.cend[tid] = dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
     }
+    for (uint32_t round = 0; round < nchunk; ++round) {  // (bounded: the first wrong chunk is right after every round)
+        __syncthreads();  // the previous round's flag has been read by everybody
+        if (tid == 0) d.changed = 0;
+        uint32_t want = start;
+        if (mine && tid > 0) want = d.cend[tid - 1];
+        __syncthreads();  // everybody has read its predecessor's end before anybody rewrites its own
+        if (mine && want != start) {
+            start = want;
+            spec_err = 0;
+            produced = 0;
+            d.cend[tid] = start >= limit ? start : dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
+            d.changed = 1;
+        }
+        __syncthreads();
+        if (!d.changed) break;
+    }
+    // Every chunk now starts where its predecessor ended: the starts are the true code boundaries.  The chunk that holds the
+    // end of the data may have decoded the final byte's pad bits as codes, and the chunks behind it decode nothing real:
+    // the final pass is therefore also bounded by the byte count, as the reference's decoder is (hzr_decode.c:463-567).
+    const uint32_t mycount = mine ? produced : 0u;
+    const uint32_t incl = wave_scan_add(mycount);
+    if (l == 63) d.wsum[w] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t i = 0; i < w; ++i) pre += d.wsum[i];
+    const uint32_t o0 = pre + incl - mycount;  // exact for every chunk up to the one that holds the end
+    uint32_t e2 = 0, p2 = 0;
+    if (mine && start < limit && o0 < out_size) dec_chunk<true>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+    // sound iff no bad code was met and exactly out_size bytes came out
+    const uint32_t inc2 = wave_scan_add(p2);
+    __syncthreads();  // (wsum is reused)
+    if (l == 63) d.wsum[w] = inc2;
+    __syncthreads();
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < kDecThreads / 64; ++i) total += d.wsum[i];
+    const uint32_t bad = (e2 || total != out_size) ? 1u : 0u;
+    if (__syncthreads_or((int)bad) && tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
 }
 
 // ---------------------------------------------------------------------------
