@@ -94,21 +94,23 @@ constexpr uint32_t kLutSlow = 0xFFFFFFFFu;
 constexpr uint32_t kDecThreads = 1024;
 constexpr uint32_t kDecMinChunkBits = 256;
 
+constexpr uint32_t kNodeSlots = 528;
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
-    uint32_t lut[1u << kLutBits];        // sym | len<<9
-    uint16_t child[2 * kNumSym][2];
-    int16_t nsym[2 * kNumSym];  // >= 0: leaf symbol
+    uint32_t lut[1u << kLutBits];        // code of <= 10 bits: sym | len<<9;  longer: kLutLong | node reached after 10 bits
+    uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
+    uint16_t anc[32];                    // tree parse: the branch node at each depth of the current path
     uint32_t leaf_code[kSymStride];
     uint16_t leaf_meta[kSymStride];  // sym | len<<9
-    uint16_t stack[64][2];           // (node, depth) -- codes travel in a parallel array
-    uint32_t stack_code[64];
-    uint32_t cstart[kDecThreads], cend[kDecThreads];  // first bit a chunk decodes from / first code boundary past its end
+    uint32_t cend[kDecThreads];  // first code boundary past a chunk's end
     uint32_t wsum[kDecThreads / 64];
     uint32_t nleaf;
     uint32_t err;
     uint32_t changed;
+    uint32_t code0;  // first bit of the codes
 };
+constexpr uint32_t kLutLong = 0x80000000u;
+constexpr uint32_t kNodeLeaf = 0x80000000u;
 
 // 32 stream bits starting at absolute bit position `bp` of the LDS image
 __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
@@ -117,64 +119,117 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
     return (uint32_t)(v >> sh);
 }
 
+// One assembled output dword to memory.  A byte that is zero in `acc` is a zero-run byte (already zero in the output) or
+// belongs to a neighbour chunk (which may be writing it right now): only the non-zero bytes are stored, as one dword when
+// all four are there (the common case in a dense plane), else one by one.
+__device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t acc) {
+    if ((acc & 0x000000FFu) && (acc & 0x0000FF00u) && (acc & 0x00FF0000u) && (acc & 0xFF000000u)) {
+        reinterpret_cast<uint32_t*>(out)[dw] = acc;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            const uint32_t v = (acc >> (8 * q)) & 0xFFu;
+            if (v) out[dw * 4 + q] = (uint8_t)v;
+        }
+    }
+}
+
 // Decode from bit `bp` until a code boundary >= `limit` (or the end of the payload).  Returns that boundary; `produced`
 // = output bytes of the tokens decoded.  WRITE: literals go to out[o0...] (bounded by out_size).
 // max_out: stop as soon as that many output bytes are produced (the last chunk: the final byte's pad bits are not codes).
+// The stream bits travel in a 64-bit register window that is refilled from LDS when fewer than 48 remain (a token is at
+// most 31 + 14 bits): one LDS access per ~4 tokens instead of two per token.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint32_t limit, uint32_t bit_end, uint32_t& produced, uint8_t* out,
                                               uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
     uint32_t o = o0;
+    unsigned long long win = 0;
+    uint32_t navail = 0;
+    uint32_t cur_dw = 0xFFFFFFFFu, acc = 0;  // WRITE: aligned output dword being assembled
     while (bp < limit && o - o0 < max_out) {
-        const uint32_t bits = peek32(d.stage, bp);
+        if (navail < 48) {
+            const uint32_t wi = bp >> 5, sh = bp & 31u;
+            win = ((unsigned long long)d.stage[wi] | ((unsigned long long)d.stage[wi + 1] << 32)) >> sh;
+            navail = 64 - sh;  // >= 33; the bits past navail are zero, a token that needs them is past bit_end anyway
+            if (navail < 48) {  // sh > 16: top up with the third word
+                win |= (unsigned long long)d.stage[wi + 2] << navail;
+                navail += 32;  // (only the low 64 bits are kept: navail is capped below)
+                navail = navail > 64 ? 64 : navail;
+            }
+        }
+        const uint32_t bits = (uint32_t)win;
         const uint32_t e = d.lut[bits & ((1u << kLutBits) - 1u)];
         uint32_t sym, len;
-        if (e != kLutSlow) {
+        if (!(e & kLutLong)) {
             sym = e & 511u;
             len = e >> 9;
         } else {
-            uint32_t nd = 0;
-            len = 0;
-            while (d.nsym[nd] < 0 && len < 32) {
-                nd = d.child[nd][(bits >> len) & 1u];
-                ++len;
-            }
-            if (d.nsym[nd] < 0) {  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
+            // a code longer than the table index: walk on from the node the first 10 bits lead to (one LDS read per level).
+            // With 64 lanes in step some lane is here at almost every token, so this path has to be short.
+            if (e == kLutSlow) {  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
                 err = 1;
                 break;
             }
-            if (len == 0) len = 1;  // single-leaf tree: one bit per symbol (hzr_decode.c:463-470)
-            sym = (uint32_t)d.nsym[nd];
+            uint32_t nd = e & 1023u, wv = d.node[nd];
+            len = kLutBits;
+            while (!(wv & kNodeLeaf) && len < 32) {
+                nd = min(((bits >> len) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
+                wv = d.node[nd];
+                ++len;
+            }
+            if (!(wv & kNodeLeaf)) {
+                err = 1;
+                break;
+            }
+            sym = wv & 511u;
         }
-        bp += len;
+        uint32_t used = len;
         if (sym < 256) {
-            if (WRITE && sym && o < out_size) out[o] = (uint8_t)sym;
+            if (WRITE && o < out_size) {
+                // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
+                // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
+                const uint32_t dw = o >> 2;
+                if (dw != cur_dw) {
+                    if (acc) flush_dword(out, cur_dw, acc);
+                    cur_dw = dw;
+                    acc = 0;
+                }
+                acc |= sym << ((o & 3u) * 8);
+            }
             ++o;
         } else {
             const uint32_t eb = run_extra_bits(sym);
             uint32_t z = sym == 256 ? 2u : sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : 279u;
-            if (eb) {
-                z += peek32(d.stage, bp) & ((1u << eb) - 1u);
-                bp += eb;
-            }
+            z += (uint32_t)(win >> len) & ((1u << eb) - 1u);
+            used += eb;
             o += z;
         }
+        win >>= used;
+        navail -= used;
+        bp += used;
         if (bp > bit_end) {  // ran over the payload
             err = 1;
             break;
         }
     }
+    if (WRITE && acc) flush_dword(out, cur_dw, acc);
     produced = o - o0;
     return bp;
 }
 
 __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
                                                           const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
-                                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed) {
+                                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
+                                                          unsigned long long* __restrict__ stamps) {
     __shared__ DecLds d;
-    const uint32_t k = blockIdx.x, j = blockIdx.y, b = blockIdx.z;
+    // workgroup -> hzr block, plane-major (grid.x = blocks * nblk, grid.y = plane): with the plane fastest the dense
+    // plane-0 blocks would all land on the XCDs 0 and 4 (workgroup i goes to XCD i % 8)
+    const uint32_t k = blockIdx.y, j = blockIdx.x % g.nblk, b = blockIdx.x / g.nblk;
     if (k >= *nb_state) return;
     const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint32_t hb = hb_index(g, b, k, j);
+#define DEC_STAMP(i) do { if (stamps && tid == 0 && hb < 512u) stamps[hb * 8u + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    DEC_STAMP(0);
     const uint64_t off = blk_off[hb];
     if (off == ~0ull) return;
     const uint8_t* s = src + (size_t)b * src_stride + off;
@@ -194,7 +249,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     const uint8_t* abase = pay - skew;
     for (uint32_t o = tid * 16; o < skew + L; o += kDecThreads * 16)
         *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
-    if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // peek32 reads one word past the last payload word
+    if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // the bit window reads up to two words past the last payload word
+    for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;  // (the tree parse below writes into it)
     __syncthreads();
 
     if (mode == kModeCopy) {  // hzr_decode.c:351-359
@@ -216,58 +272,72 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
 
     // ---- Huffman + RLE -------------------------------------------------------
     for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);  // zero runs = untouched bytes
-    for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;
     const uint32_t bit0 = skew * 8, bit_end = (skew + L) * 8;
+    DEC_STAMP(1);
     if (tid == 0) {
-        // RecoverTree (hzr_decode.c:263-333), iteratively, pre-order: child_a first
-        uint32_t bp = bit0, nn = 1, sp = 0, nleaf = 0, err = 0;
-        d.stack[0][0] = 0;
-        d.stack[0][1] = 0;
-        d.stack_code[0] = 0;
-        sp = 1;
-        while (sp > 0 && !err) {
-            --sp;
-            const uint32_t nd = d.stack[sp][0], depth = d.stack[sp][1], code = d.stack_code[sp];
-            if (bp + 10 > bit_end + 9 || bp >= bit_end) {
+        // RecoverTree (hzr_decode.c:263-333) without a stack: nodes are numbered in pre-order (child_a = id + 1), the
+        // current path lives in two registers (code bits LSB-first = root first, depth), and after a leaf the parse
+        // resumes at child_b of the deepest ancestor whose child_a subtree it has just finished.
+        uint32_t bp = bit0, nn = 0, nleaf = 0, err = 0, code = 0, depth = 0;
+        unsigned long long win = 0;
+        uint32_t navail = 0;
+        bool done = false;
+        while (!done && !err) {
+            if (bp >= bit_end) {
                 err = 1;
                 break;
             }
-            const uint32_t bits = peek32(d.stage, bp);
-            if (bits & 1u) {
-                const uint32_t sym = (bits >> 1) & 511u;
+            if (navail < 10) {
+                const uint32_t wi = bp >> 5, sh = bp & 31u;
+                win = ((unsigned long long)d.stage[wi] | ((unsigned long long)d.stage[wi + 1] << 32)) >> sh;
+                navail = 64 - sh;
+            }
+            const uint32_t nd = nn++;
+            if (nd >= 2u * kNumSym - 1) {
+                err = 1;
+                break;
+            }
+            if ((uint32_t)win & 1u) {  // leaf: '1' + 9-bit symbol
+                const uint32_t sym = ((uint32_t)win >> 1) & 511u;
+                win >>= 10;
+                navail -= 10;
                 bp += 10;
                 if (sym > 260 || nleaf >= (uint32_t)kNumSym) {
                     err = 1;
                     break;
                 }
-                d.nsym[nd] = (int16_t)sym;
+                d.node[nd] = kNodeLeaf | sym;
                 d.leaf_code[nleaf] = code;
                 d.leaf_meta[nleaf] = (uint16_t)(sym | (depth << 9));
                 ++nleaf;
-            } else {
+                // up: drop the decisions that were already child_b, then turn the last child_a into child_b
+                while (depth > 0 && ((code >> (depth - 1)) & 1u)) {
+                    --depth;
+                    code &= ~(1u << depth);
+                }
+                if (depth == 0) {
+                    done = true;
+                } else {
+                    code |= 1u << (depth - 1);
+                    d.node[d.anc[depth - 1]] = nn;  // that ancestor's child_b is the next node
+                }
+            } else {  // branch: '0', then child_a
+                win >>= 1;
+                navail -= 1;
                 bp += 1;
-                if (nn + 2 > 2u * kNumSym - 1 || sp + 2 > 64 || depth >= 31) {
+                if (depth >= 31) {
                     err = 1;
                     break;
                 }
-                d.nsym[nd] = -1;
-                d.child[nd][0] = (uint16_t)nn;
-                d.child[nd][1] = (uint16_t)(nn + 1);
-                d.stack[sp][0] = (uint16_t)(nn + 1);  // child_b is read after child_a's whole subtree
-                d.stack[sp][1] = (uint16_t)(depth + 1);
-                d.stack_code[sp] = code | (1u << depth);
-                ++sp;
-                d.stack[sp][0] = (uint16_t)nn;
-                d.stack[sp][1] = (uint16_t)(depth + 1);
-                d.stack_code[sp] = code;
-                ++sp;
-                nn += 2;
+                if (depth == kLutBits) d.lut[code] = kLutLong | nd;  // codes longer than the table index continue from here
+                d.anc[depth] = (uint16_t)nd;
+                ++depth;  // (the new decision bit is 0)
             }
         }
         if (bp > bit_end) err = 1;
         d.nleaf = nleaf;
         d.err = err;
-        d.stack_code[63] = bp;  // where the codes start
+        d.code0 = bp;  // where the codes start
     }
     __syncthreads();
     if (d.err) {
@@ -283,8 +353,10 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
         if (elen <= kLutBits)
             for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = (meta & 511u) | (elen << 9);
     }
-    const uint32_t code0 = d.stack_code[63];
+    const uint32_t code0 = d.code0;
+    DEC_STAMP(2);
     __syncthreads();
+    DEC_STAMP(3);
 
     // ---- chunks ---------------------------------------------------------------
     const uint32_t nbits = bit_end - code0;
@@ -295,10 +367,13 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     const uint32_t limit = tid + 1 == nchunk ? bit_end : min(bit_end, code0 + (tid + 1) * S);
     uint32_t start = code0 + tid * S, produced = 0, spec_err = 0;
     if (mine) {
-        d.cstart[tid] = start;
         d.cend[tid] = dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
     }
+#ifdef RSPT_DEC_ONEROUND
+    for (uint32_t round = 0; round < 1; ++round) {
+#else
     for (uint32_t round = 0; round < nchunk; ++round) {  // (bounded: the first wrong chunk is right after every round)
+#endif
         __syncthreads();  // the previous round's flag has been read by everybody
         if (tid == 0) d.changed = 0;
         uint32_t want = start;
@@ -314,6 +389,7 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
         __syncthreads();
         if (!d.changed) break;
     }
+    DEC_STAMP(4);
     // Every chunk now starts where its predecessor ended: the starts are the true code boundaries.  The chunk that holds the
     // end of the data may have decoded the final byte's pad bits as codes, and the chunks behind it decode nothing real:
     // the final pass is therefore also bounded by the byte count, as the reference's decoder is (hzr_decode.c:463-567).
@@ -325,16 +401,23 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     for (uint32_t i = 0; i < w; ++i) pre += d.wsum[i];
     const uint32_t o0 = pre + incl - mycount;  // exact for every chunk up to the one that holds the end
     uint32_t e2 = 0, p2 = 0;
+#ifdef RSPT_DEC_NOWRITE
+    if (mine && start < limit && o0 < out_size) dec_chunk<false>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+#else
     if (mine && start < limit && o0 < out_size) dec_chunk<true>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+#endif
     // sound iff no bad code was met and exactly out_size bytes came out
     const uint32_t inc2 = wave_scan_add(p2);
     __syncthreads();  // (wsum is reused)
+    DEC_STAMP(5);
     if (l == 63) d.wsum[w] = inc2;
     __syncthreads();
     uint32_t total = 0;
     for (uint32_t i = 0; i < kDecThreads / 64; ++i) total += d.wsum[i];
     const uint32_t bad = (e2 || total != out_size) ? 1u : 0u;
     if (__syncthreads_or((int)bad) && tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+    DEC_STAMP(6);
+#undef DEC_STAMP
 }
 
 // ---------------------------------------------------------------------------

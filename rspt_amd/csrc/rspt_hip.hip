@@ -772,8 +772,8 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
         HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
                            d_consumed, p->means);
-        hipLaunchKernelGGL(k_dec_block, dim3(kMaxPlanes, g.nblk, B), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
-                           d_consumed);
+        hipLaunchKernelGGL(k_dec_block, dim3(g.nblk * B, kMaxPlanes), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
+                           d_consumed, p->ablate ? p->stamps : nullptr);
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
         if (xd) {
