@@ -45,12 +45,20 @@ struct CrcConsts {
     //   shift[i][j][b] = gf_mul(b << 8j, K_i),  K_i = x^(8*64*(63-i)) for i < 64 (lane chunk -> end of the wave's 4 KiB slot),
     //   K_{64+w} = x^(8*4096*(15-w)) (wave slot -> end of the 64 KiB window), K_80 = x^(8*65536) (the one chunk in front of it)
     uint32_t shift[81][4][256];
+    // shift4[l] = multiplication by x^(8*4*(l+1)): a lane's word-strided partial CRC to the end of its 64-word group
+    // (the big encoder's CRC: lane tid owns the virtual words tid, tid+1024, ... counted from the END of the image)
+    uint32_t shift4[64][4][256];
     uint32_t prefix;  // 4 bytes X (LE) with raw_crc(X) = 0xFFFFFFFF
     uint32_t pad[3];
 };
 
 __device__ __forceinline__ uint32_t gf_shift(const CrcConsts* cc, uint32_t i, uint32_t a) {
     const uint32_t(*t)[256] = cc->shift[i];
+    return t[0][a & 0xFFu] ^ t[1][(a >> 8) & 0xFFu] ^ t[2][(a >> 16) & 0xFFu] ^ t[3][a >> 24];
+}
+
+__device__ __forceinline__ uint32_t gf_shift4(const CrcConsts* cc, uint32_t i, uint32_t a) {
+    const uint32_t(*t)[256] = cc->shift4[i];
     return t[0][a & 0xFFu] ^ t[1][(a >> 8) & 0xFFu] ^ t[2][(a >> 16) & 0xFFu] ^ t[3][a >> 24];
 }
 

@@ -713,14 +713,13 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
 // ===========================================================================
 // k_encode
 // ===========================================================================
-// The payload image lives in LDS with one pad word after every 16 words, so
-// that both access patterns are bank-conflict free: consecutive words by
-// consecutive lanes (emit, copy-out) and one 64-byte chunk per lane (CRC).
-// Logical word 0 holds the CRC prefix X, the payload starts at logical byte 4: the image IS the
-// virtual CRC input V = X || payload (tools/kernel_model.py:crc_parallel).
-__device__ __forceinline__ uint32_t skew(uint32_t w) { return w + (w >> 4); }
-constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;                    // logical words (X + payload + read slack)
-constexpr uint32_t kStagePhys = kStageWords + (kStageWords >> 4) + 2;   // physical words
+// The payload image lives in LDS as plain consecutive words.  Logical word 0 holds the CRC prefix X, the payload starts at
+// byte 4: the image IS the virtual CRC input V = X || payload.  Both access patterns are bank-conflict free without
+// padding: consecutive words by consecutive lanes (emit, copy-out), and the CRC reads word-strided -- lane tid owns
+// the virtual words tid, tid + 1024, ... counted from the END of V (tools/kernel_model.py:crc_strided).
+__device__ __forceinline__ uint32_t skew(uint32_t w) { return w; }  // (kept as the one place that maps a logical word to LDS)
+constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;  // X + payload + read slack
+constexpr uint32_t kStagePhys = kStageWords + 2;
 
 constexpr uint32_t kRunClsEntries = 280;  // lengths 0..278 and ">= 279" (hzr_internal.h:117-121)
 __device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
@@ -731,7 +730,7 @@ __device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
 
 struct EncLds {
     uint32_t cw[kSymStride];  // first: the lookups address it with an immediate offset (16 bits)
-    uint32_t crc[4][256];
+    uint32_t crc[4][256];  // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
     uint32_t scr[2 * kEncWaves];
     uint32_t wsum[kEncWaves];
     uint32_t crc_out;
@@ -992,23 +991,6 @@ __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, 
 // byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
 __device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[skew(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }
 
-// raw CRC state (from 0) after the 64 bytes [lo, lo+64) of V; bytes in front of V (lo < 0) are zero
-__device__ __forceinline__ uint32_t crc_chunk64(const EncLds& d, int32_t lo) {
-    const int32_t a = lo >> 2;  // arithmetic: floor
-    const uint32_t sh = (uint32_t)lo & 3u;
-    uint32_t c = 0;
-    uint32_t prev = a >= 0 ? d.stage[skew((uint32_t)a)] : 0u;
-#pragma unroll
-    for (int32_t q = 0; q < 16; ++q) {
-        const int32_t ix = a + q + 1;
-        const uint32_t next = ix >= 0 ? d.stage[skew((uint32_t)ix)] : 0u;
-        c ^= __builtin_amdgcn_alignbyte(next, prev, sh);
-        prev = next;
-        c = d.crc[3][c & 0xFFu] ^ d.crc[2][(c >> 8) & 0xFFu] ^ d.crc[1][(c >> 16) & 0xFFu] ^ d.crc[0][c >> 24];
-    }
-    return c;
-}
-
 // `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
 // emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
 // The workgroup-per-block encoder's LDS lives at namespace scope so that encode_block can be a
@@ -1142,21 +1124,31 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
     __syncthreads();
     RSPT_STAMP(5);
 
-    // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0), cut into 64-byte
-    //      chunks counted from its END; lane tid owns chunk (1023 - tid); crc = ~raw(V) --------
+    // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0) as 4-byte virtual words counted from its END;
+    //      lane tid owns the words tid, tid + 1024, ... (consecutive lanes read consecutive LDS words), Horner over its
+    //      words with x^(8*4096) per step, then x^(8*4*(tid+1)) to the end of V; crc = ~raw(V) -------------------------
     {
         const int32_t Lv = (int32_t)L + 4;
-        const int32_t hi = Lv - 64 * (int32_t)(kEncThreads - 1 - tid);
+        const uint32_t nvw = (uint32_t)(Lv + 3) >> 2;
+        const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;  // steps of the fullest lane (block-uniform)
+        auto vword = [&](uint32_t r) -> uint32_t {  // bytes [Lv - 4(r+1), Lv - 4r) of V; bytes in front of V are zero
+            const int32_t lo = Lv - 4 * (int32_t)(r + 1);
+            const int32_t a = lo >> 2;  // arithmetic: floor
+            const uint32_t w_lo = a >= 0 ? d.stage[a] : 0u, w_hi = d.stage[a + 1];
+            return __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)lo & 3u);
+        };
         uint32_t c = 0;
-        if (hi > 0 && !(ablate & 2u)) c = crc_chunk64(d, hi - 64);
-        if (__ballot(c != 0)) {  // waves without data skip the shift
-            const uint32_t red = wave_xor_u32(gf_shift(cc, l, c));
-            if (l == 0) {
-                uint32_t v = gf_shift(cc, 64 + w, red);
-                // the only chunk that can precede the 64 KiB window (Lv > 65536)
-                if (w == 0 && Lv > (int32_t)kHzrBlock) v ^= gf_shift(cc, 80, crc_chunk64(d, Lv - 64 * (int32_t)kEncThreads - 64));
-                d.wsum[w] = v;
+        if (tid < nvw && !(ablate & 2u)) {
+            for (uint32_t k = K - 1; k >= 1; --k) {
+                const uint32_t r = tid + kEncThreads * k;
+                if (r < nvw) c ^= vword(r);
+                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];  // * x^(8*4096)
             }
+            c ^= vword(tid);
+        }
+        if (__ballot(c != 0)) {  // waves without data skip the shifts
+            const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));  // every lane to the end of the wave's 64 words
+            if (l == 0) d.wsum[w] = gf_shift(cc, 63u - 4u * w, red);  // x^(8*256*w): the wave's group to the end of V
         } else if (l == 0) {
             d.wsum[w] = 0;
         }
@@ -1205,7 +1197,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
 // as floor(R/16662) capped tokens plus a remainder token -- the same token sequence as the
 // reference's greedy walk (hzr_encode.c:410-457).  Zero 4 KiB segments are skipped without a read.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kSlotWords = kStagePhys / kEncWaves;  // per-wave LDS slot: [cw 264][image]
+constexpr uint32_t kSlotWords = 1090;  // per-wave LDS slot of the small-block encoder: [cw 264][image]
 constexpr uint32_t kSlotImage = kSlotWords - kSymStride;  // words of X || payload (+ slack)
 static_assert(kSlotImage * 4 >= kSmallPayload + 4 + 72, "small-block slot too small");
 
@@ -1439,7 +1431,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
                                                           const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase,
                                                           const uint32_t* __restrict__ zbza) {
     __shared__ uint32_t s_slot;
-    (&g_enc.crc[0][0])[threadIdx.x] = (&cc->table[0][0])[threadIdx.x];  // 1024 threads, 4 x 256 entries, once per workgroup
+    (&g_enc.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_enc.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     const uint32_t n_big = wq->n_big;
     // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the

@@ -58,6 +58,11 @@ void make_crc_consts(CrcConsts& cc) {
         for (int jx = 0; jx < 4; ++jx)
             for (uint32_t b = 0; b < 256; ++b) cc.shift[i][jx][b] = gf_mul(b << (8 * jx), K);
     }
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t K = x_pow_bytes(4ull * (l + 1));
+        for (int jx = 0; jx < 4; ++jx)
+            for (uint32_t b = 0; b < 256; ++b) cc.shift4[l][jx][b] = gf_mul(b << (8 * jx), K);
+    }
     // X with raw_crc(X) = 0xFFFFFFFF: the 4-byte raw CRC map is linear and invertible
     uint32_t img[32];
     for (int b = 0; b < 32; ++b) img[b] = raw_crc4(1u << b);

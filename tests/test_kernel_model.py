@@ -73,3 +73,14 @@ def test_parallel_crc_equals_oracle(orc):
         assert km.crc_parallel(m, lanes=4, waves=2) == orc.crc32c(m), n
     m = r.randint(0, 256, 3000).astype(np.uint8).tobytes()
     assert km.crc_parallel(m, lanes=64, waves=16) == orc.crc32c(m)
+
+
+def test_strided_crc_equals_oracle(orc):
+    """the big encoder's CRC: word-strided lanes over the unpadded image (hzr_kernels.hip: encode_block)"""
+    r = np.random.RandomState(12)
+    for n in (1, 2, 3, 4, 5, 12, 15, 16, 17, 28, 29, 63, 64, 65, 255, 256, 257, 1000, 1023, 1024, 1025, 5000):
+        m = r.randint(0, 256, n).astype(np.uint8).tobytes()
+        assert km.crc_strided(m, nthr=8) == orc.crc32c(m), n
+        assert km.crc_strided(m, nthr=64) == orc.crc32c(m), n
+    m = r.randint(0, 256, 9000).astype(np.uint8).tobytes()
+    assert km.crc_strided(m, nthr=1024) == orc.crc32c(m)

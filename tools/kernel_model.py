@@ -266,6 +266,34 @@ def crc_parallel(msg, lanes=64, waves=16):
     return total ^ 0xFFFFFFFF
 
 
+def crc_strided(msg, nthr=1024):
+    """CRC-32C of msg the way the big encoder does it on its unpadded LDS image: V = X || msg as 4-byte virtual words
+    counted from the END; thread tid owns the words tid, tid + nthr, ... (consecutive threads read consecutive
+    words: no bank conflicts), Horner over its words with x^(8*4*nthr) per step, then x^(8*4*(tid+1)) to the end."""
+    X = init_prefix()
+    V = X + bytes(msg)
+    Lv = len(V)
+    nvw = (Lv + 3) // 4
+
+    def vword(r):
+        lo = Lv - 4 * (r + 1)
+        return int.from_bytes(bytes(V[p] if p >= 0 else 0 for p in range(lo, lo + 4)), "little")
+
+    K = (nvw + nthr - 1) // nthr
+    G = x_pow_bytes(4 * nthr)
+    total = 0
+    for tid in range(min(nthr, nvw)):
+        c = 0
+        for k in range(K - 1, 0, -1):
+            r = tid + nthr * k
+            if r < nvw:
+                c ^= vword(r)
+            c = gf_mul(c, G)
+        c ^= vword(tid)
+        total ^= gf_mul(c, x_pow_bytes(4 * (tid + 1)))
+    return total ^ 0xFFFFFFFF
+
+
 def crc_constants(lanes=64, waves=16):
     return dict(
         prefix=int.from_bytes(init_prefix(), "little"),
