@@ -220,10 +220,33 @@ __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t 
                                           uint32_t za, uint32_t* s_hist) {
     const GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t w[4] = {w0, w1, w2, w3};
+    // tokens without extra bits: literals, lone zeros (symbol 0 = byte value 0), two zeros (symbol 256).  Three
+    // wave-uniform shapes of the row:
+    if (!__ballot(__popc(m.single) > 4)) {
+        // sparse: a few tokens per lane -- walk them (16 predicated adds would mostly add nothing)
+        uint32_t t = m.single;
+        while (t) {
+            const uint32_t i = (uint32_t)__builtin_ctz(t);
+            t &= t - 1;
+            atomicAdd(&s_hist[granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8)], 1u);
+        }
+    } else if (!__ballot(__popc(zm & ~m.single) > 2)) {
+        // dense and clean (hardly any zero byte that starts no token): every byte adds its token bit to the bin of its
+        // value, unpredicated; the few two-zero tokens are moved from bin 0 to bin 256 afterwards.  (Not for rows with
+        // many dead zeros: same-address LDS atomics serialise even when they add 0.)
 #pragma unroll
-    for (uint32_t i = 0; i < 16; ++i) {
-        const uint32_t x = ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) | (((m.two >> i) & 1u) << 8);
-        if ((m.single >> i) & 1u) atomicAdd(&s_hist[x], 1u);  // literal, lone zero (symbol 0) or two zeros (symbol 256)
+        for (uint32_t i = 0; i < 16; ++i) atomicAdd(&s_hist[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu], (m.single >> i) & 1u);
+        if (m.two) {
+            const uint32_t n2 = (uint32_t)__popc(m.two);
+            atomicAdd(&s_hist[0], 0u - n2);
+            atomicAdd(&s_hist[256], n2);
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) {
+            const uint32_t x = ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) | (((m.two >> i) & 1u) << 8);
+            if ((m.single >> i) & 1u) atomicAdd(&s_hist[x], 1u);
+        }
     }
     uint32_t st = m.runs;
     while (st) {
