@@ -174,7 +174,7 @@ def main():
                 else:
                     # the index only: every rank learns the size of every stream of the step (ncclAllGather of
                     # the per-block sizes); device tensors, no host round trip
-                    dist.all_gather_into_tensor(sizes_all[slot], d_sizes[slot])
+                    dist.all_gather(list(sizes_all[slot].unbind(0)), d_sizes[slot])
                 slot_free[slot] = torch.cuda.Event()
                 slot_free[slot].record(side)
 

@@ -43,6 +43,11 @@ def _worker(rank, world, port, q):
     packed = torch.frombuffer(bytearray(cont), dtype=torch.uint8)
     total = torch.tensor([len(cont)], dtype=torch.int64)
     got = shard.gather_containers(packed, total, dst=0)
+    # the per-step exchange of bench.py: every rank learns the size of every stream (an equal count per rank there)
+    mine = torch.tensor([len(x) for x in streams[:3]], dtype=torch.int64)
+    everyone = torch.zeros((world, 3), dtype=torch.int64)
+    dist.all_gather(list(everyone.unbind(0)), mine)
+    assert everyone[rank].tolist() == mine.tolist() and (everyone > 0).all()
     if rank == 0:
         q.put([bytes(t[:n].numpy().tobytes()) for t, n in got])
     dist.barrier()
