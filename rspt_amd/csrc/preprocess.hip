@@ -152,7 +152,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     uint32_t work = skip_untouched(blockIdx.x);
     // The first item of a tile is loaded before the previous tile's rows are stored: vmcnt retires in issue order, so a
     // load issued behind 18 KiB of stores would wait for their write acknowledgements before the tile could start.
-    ItemRegs cur, nxt;
+    ItemRegs cur, nxt, nx2;
     if (work < total) {
         const uint32_t s0f = tile_s0(work), Tnf = min(T, g.ns - s0f);
         const uint8_t* blkf = src + (size_t)(work / tiles_per_block) * g.block_bytes;
@@ -185,10 +185,12 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     uint32_t nz_seg = 0xFFFFFFFFu, nz_done = 0;  // segment (flat index >> 12) this thread is in, planes already flagged for it
     uint32_t q = tid;
     bool have = q < nitems;  // (item `tid` is in `cur` already)
+    if (q + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, q + nthr, nxt);
     while (have) {
         const uint32_t qn = q + nthr;
         const bool have_next = qn < nitems;
-        if (have_next) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, qn, nxt);
+        // two items ahead: ~36 row-segment loads (9 KiB) in flight per wave while this item is transformed
+        if (qn + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, qn + nthr, nx2);
         const uint32_t grp = fast_div(q, g.nch, m_nch);
         const uint32_t c = q - grp * g.nch;
         const uint32_t t0 = grp << 4;
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
             }
         }
         cur = nxt;
+        nxt = nx2;
         q = qn;
         have = have_next;
     }
