@@ -806,6 +806,14 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
         const uint32_t T = min(p->Tn_native, g.ns);
         const uint32_t lds = g.nch * (T + 1) * 4;
         const dim3 ng((g.ns + T - 1) / T, B);
+        if (g.bps == 4 && (g.nch & 3) == 0 && (g.ns & 3) == 0 && g.nch <= 1024 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0) {
+            // T4 samples x nch channels in at most 32 KiB of LDS (four workgroups per CU), T4 a multiple of 4
+            uint32_t T4 = (uint32_t)((32768ull / (4ull * g.nch) - 1) & ~3ull);
+            T4 = T4 > 1024 ? 1024 : T4 < 4 ? 4 : T4;
+            if (T4 > g.ns) T4 = g.ns;
+            hipLaunchKernelGGL(k_planar_native_i32x4, dim3((g.ns + T4 - 1) / T4, B), dim3(256), g.nch * (T4 + 1) * 4, st, final_planar, g, T4,
+                               (uint8_t*)d_dst);
+        } else
         switch (g.bps) {
             case 1: hipLaunchKernelGGL((k_planar_native<1>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
             case 2: hipLaunchKernelGGL((k_planar_native<2>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
