@@ -99,12 +99,11 @@ struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
     uint32_t lut[1u << kLutBits];        // code of <= 10 bits: sym | len<<9;  longer: kLutLong | node reached after 10 bits
     uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
-    uint16_t anc[32];                    // tree parse: the branch node at each depth of the current path
     uint32_t leaf_code[kSymStride];
     uint16_t leaf_meta[kSymStride];  // sym | len<<9
     uint32_t cend[kDecThreads];  // first code boundary past a chunk's end
     uint32_t wsum[kDecThreads / 64];
-    uint32_t nleaf;
+    uint32_t nleaf, nnode;
     uint32_t err;
     uint32_t changed;
     uint32_t code0;  // first bit of the codes
@@ -274,88 +273,112 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);  // zero runs = untouched bytes
     const uint32_t bit0 = skew * 8, bit_end = (skew + L) * 8;
     DEC_STAMP(1);
+    // RecoverTree (hzr_decode.c:263-333) in three steps.  The description is pre-order: '1' + 9-bit symbol = leaf, '0' = branch
+    // followed by child_a then child_b.  Nodes are numbered in pre-order, so child_a = id + 1.
+    //   A (one lane, scalar unit): cut the bit string into nodes; keep the count of subtrees still open after each
+    //   B (a thread per node): a branch finds the end of its child_a subtree -- the first later node after which one subtree
+    //     fewer is open than after the branch itself -- and so its child_b; parent links follow
+    //   C (a thread per node): walk up to the root for depth and code; leaves fill the tables, branches at depth 10 mark
+    //     where codes longer than the table index continue
+    uint16_t* t_open = reinterpret_cast<uint16_t*>(d.cend);  // (the chunk array is not in use yet)
+    uint16_t* t_par = t_open + kNodeSlots;                     // parent | child_b? << 15
+    uint16_t* t_ord = t_par + kNodeSlots;                      // leaf ordinal
+    static_assert(3 * kNodeSlots * sizeof(uint16_t) <= sizeof(d.cend), "tree scratch does not fit");
     if (tid == 0) {
-        // RecoverTree (hzr_decode.c:263-333) without a stack: nodes are numbered in pre-order (child_a = id + 1), the
-        // current path lives in two registers (code bits LSB-first = root first, depth), and after a leaf the parse
-        // resumes at child_b of the deepest ancestor whose child_a subtree it has just finished.
-        uint32_t bp = bit0, nn = 0, nleaf = 0, err = 0, code = 0, depth = 0;
+        uint32_t bp = bit0, nn = 0, nleaf = 0, err = 0, open = 1;
         unsigned long long win = 0;
         uint32_t navail = 0;
-        bool done = false;
-        while (!done && !err) {
-            if (bp >= bit_end) {
+        while (open && !err) {
+            if (bp >= bit_end || nn >= 2u * kNumSym - 1) {
                 err = 1;
                 break;
             }
             if (navail < 10) {
+                // (readfirstlane: one lane runs this loop, so everything it computes is wave-uniform and the compiler
+                // keeps the parse state in SGPRs, on the scalar unit)
                 const uint32_t wi = bp >> 5, sh = bp & 31u;
-                win = ((unsigned long long)d.stage[wi] | ((unsigned long long)d.stage[wi + 1] << 32)) >> sh;
+                const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.stage[wi]);
+                const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.stage[wi + 1]);
+                win = ((unsigned long long)w_lo | ((unsigned long long)w_hi << 32)) >> sh;
                 navail = 64 - sh;
             }
-            const uint32_t nd = nn++;
-            if (nd >= 2u * kNumSym - 1) {
+            const uint32_t leaf = (uint32_t)win & 1u;
+            const uint32_t sym = ((uint32_t)win >> 1) & 511u;
+            const uint32_t used = leaf ? 10u : 1u;
+            if (leaf && (sym > 260 || nleaf >= (uint32_t)kNumSym)) {
                 err = 1;
                 break;
             }
-            if ((uint32_t)win & 1u) {  // leaf: '1' + 9-bit symbol
-                const uint32_t sym = ((uint32_t)win >> 1) & 511u;
-                win >>= 10;
-                navail -= 10;
-                bp += 10;
-                if (sym > 260 || nleaf >= (uint32_t)kNumSym) {
-                    err = 1;
-                    break;
-                }
-                d.node[nd] = kNodeLeaf | sym;
-                d.leaf_code[nleaf] = code;
-                d.leaf_meta[nleaf] = (uint16_t)(sym | (depth << 9));
-                ++nleaf;
-                // up: drop the decisions that were already child_b, then turn the last child_a into child_b
-                while (depth > 0 && ((code >> (depth - 1)) & 1u)) {
-                    --depth;
-                    code &= ~(1u << depth);
-                }
-                if (depth == 0) {
-                    done = true;
-                } else {
-                    code |= 1u << (depth - 1);
-                    d.node[d.anc[depth - 1]] = nn;  // that ancestor's child_b is the next node
-                }
-            } else {  // branch: '0', then child_a
-                win >>= 1;
-                navail -= 1;
-                bp += 1;
-                if (depth >= 31) {
-                    err = 1;
-                    break;
-                }
-                if (depth == kLutBits) d.lut[code] = kLutLong | nd;  // codes longer than the table index continue from here
-                d.anc[depth] = (uint16_t)nd;
-                ++depth;  // (the new decision bit is 0)
-            }
+            open = leaf ? open - 1 : open + 1;
+            d.node[nn] = leaf ? (kNodeLeaf | sym) : 0u;
+            t_open[nn] = (uint16_t)open;
+            t_ord[nn] = (uint16_t)nleaf;
+            nleaf += leaf;
+            ++nn;
+            win >>= used;
+            navail -= used;
+            bp += used;
         }
         if (bp > bit_end) err = 1;
         d.nleaf = nleaf;
+        d.nnode = nn;
         d.err = err;
         d.code0 = bp;  // where the codes start
+        t_par[0] = 0;
     }
     __syncthreads();
     if (d.err) {
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
-    // LUT: every leaf with len <= 10 owns the entries code + m*2^len (code bits are LSB-first, root decision = bit 0)
-    const uint32_t nleaf = d.nleaf;
-    for (uint32_t i = tid; i < nleaf; i += kDecThreads) {
-        const uint32_t meta = d.leaf_meta[i], len = meta >> 9, code = d.leaf_code[i];
-        // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
-        const uint32_t elen = len ? len : 1u;
-        if (elen <= kLutBits)
-            for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = (meta & 511u) | (elen << 9);
+    const uint32_t nn = d.nnode, nleaf = d.nleaf;
+    for (uint32_t i = tid; i < nn; i += kDecThreads) {  // B
+        if (!(d.node[i] & kNodeLeaf)) {
+            const uint32_t want = (uint32_t)t_open[i] - 1u;  // open subtrees once child_a's subtree is read
+            uint32_t j = i + 1;
+            while (j + 1 < nn && (uint32_t)t_open[j] != want) ++j;  // (a complete description always has the match)
+            const uint32_t cb = j + 1;                               // child_b follows child_a's subtree
+            d.node[i] = cb;
+            t_par[i + 1] = (uint16_t)i;
+            t_par[cb < nn ? cb : i + 1] = (uint16_t)(i | 0x8000u);
+        }
+    }
+    __syncthreads();
+    uint32_t deep = 0;
+    for (uint32_t i = tid; i < nn; i += kDecThreads) {  // C
+        uint32_t depth = 0, cur = i;
+        while (cur != 0 && depth < 40) {
+            cur = t_par[cur] & 0x7FFFu;
+            ++depth;
+        }
+        uint32_t code = 0, dd = depth;
+        cur = i;
+        while (cur != 0 && dd > 0 && dd <= 32) {
+            const uint32_t pw = t_par[cur];
+            --dd;
+            code |= (pw >> 15) << dd;  // code bit at position = depth of the decision (root first, LSB first)
+            cur = pw & 0x7FFFu;
+        }
+        const uint32_t w_node = d.node[i];
+        if (w_node & kNodeLeaf) {
+            if (depth > 31) deep = 1;
+            const uint32_t q = t_ord[i];
+            d.leaf_code[q] = code;
+            d.leaf_meta[q] = (uint16_t)((w_node & 511u) | (depth << 9));
+            // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
+            const uint32_t elen = depth ? depth : 1u;
+            if (elen <= kLutBits)  // every leaf of <= 10 bits owns the entries code + m * 2^len
+                for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = (w_node & 511u) | (elen << 9);
+        } else if (depth == kLutBits) {
+            d.lut[code] = kLutLong | i;  // codes longer than the table index continue from here
+        }
+    }
+    if (__syncthreads_or((int)deep)) {  // deeper than the reference's decoder supports (hzr_decode.c: 32-bit codes)
+        if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+        return;
     }
     const uint32_t code0 = d.code0;
     DEC_STAMP(2);
-    __syncthreads();
     DEC_STAMP(3);
 
     // ---- chunks ---------------------------------------------------------------
