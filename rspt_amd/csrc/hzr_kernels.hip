@@ -216,13 +216,35 @@ struct GranuleRegs {  // packed to keep four of them live at the 64-VGPR budget
 __device__ __forceinline__ GranuleRegs granule_regs(const LaneBlock& L, int r) {
     return GranuleRegs{L.g[r].w[0], L.g[r].w[1], L.g[r].w[2], L.g[r].w[3], L.g[r].zm | (L.g[r].nv << 16), L.zb[r] | (L.za[r] << 16)};
 }
+// CONST: some lane of the wave holds a granule of sixteen equal non-zero bytes in this block (decided once per block)
+template <bool CONST>
 __device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
                                           uint32_t za, uint32_t* s_hist) {
-    const GranuleMasks m = granule_masks(zm, nv, zb, za);
+    GranuleMasks m = granule_masks(zm, nv, zb, za);
     const uint32_t w[4] = {w0, w1, w2, w3};
+    // A granule of sixteen equal non-zero bytes (the sign bytes of a raw plane, a flat signal): sixteen adds to one bin,
+    // from every lane of the wave at once, would serialise 1024-fold.  Such lanes add 16 once, and the lanes that share the
+    // first such lane's value add through one lane.
+    const bool uni = CONST && nv == 16 && zm == 0 && w0 == w1 && w1 == w2 && w2 == w3 && w0 == (w0 & 0xFFu) * 0x01010101u;
+    const unsigned long long um = CONST ? __ballot(uni) : 0ull;
+    if (um) {
+        const uint32_t lead = (uint32_t)__builtin_ctzll(um);
+        const uint32_t v = w0 & 0xFFu;
+        const uint32_t vlead = read_lane(v, lead);
+        const unsigned long long same = __ballot(uni && v == vlead);
+        if (uni) {
+            if (v != vlead)
+                atomicAdd(&s_hist[v], 16u);
+            else if (lane_id() == lead)
+                atomicAdd(&s_hist[v], 16u * (uint32_t)__popcll(same));
+            m.single = 0;  // (m.runs is empty: no zero byte)
+        }
+    }
     // tokens without extra bits: literals, lone zeros (symbol 0 = byte value 0), two zeros (symbol 256).  Three
     // wave-uniform shapes of the row:
-    if (!__ballot(__popc(m.single) > 4)) {
+    if (uni) {
+        // nothing left
+    } else if (!__ballot(__popc(m.single) > 4)) {
         // sparse: a few tokens per lane -- walk them (16 predicated adds would mostly add nothing)
         uint32_t t = m.single;
         while (t) {
@@ -313,12 +335,30 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         if (wave_may_have_tokens(segmask, L)) {
             uint32_t* myhist = s_hist[tid >> 6];
             GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
-#pragma unroll 1
+            // constant granules (sign bytes of a raw plane, a flat signal) need the aggregating variant; a dense xdelta plane
+            // never has one, and pays for one test per block instead of one per row
+            bool cst = false;
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                hist_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
-                q0 = q1;
-                q1 = q2;
-                q2 = q3;
+                const Granule& gg = L.g[r];
+                cst |= gg.zm == 0 && gg.w[0] == gg.w[1] && gg.w[2] == gg.w[3] && gg.w[0] == gg.w[2] && gg.w[0] == __builtin_amdgcn_perm(gg.w[0], gg.w[0], 0u);
+            }
+            if (__ballot(cst)) {
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    hist_granule<true>(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
+                    q0 = q1;
+                    q1 = q2;
+                    q2 = q3;
+                }
+            } else {
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+                    hist_granule<false>(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
+                    q0 = q1;
+                    q1 = q2;
+                    q2 = q3;
+                }
             }
         }
         __syncthreads();
