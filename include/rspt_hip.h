@@ -91,6 +91,12 @@ unsigned rspt_hip_current_nb(rspt_hip_packer* p);
 /* Set it (a decoder fed streams from another instance needs this). */
 int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb);
 
+/* Decompress normally trusts the stream like the reference does (hzr_decode.c:343 skips the block CRCs).  With
+ * verify on, every Huffman / PlainCopy block's CRC-32C is recomputed on the device and compared with its header
+ * (what hzr_verify does, hzr_decode.c:569-624); a mismatch makes the call return RSPT_HIP_ERR_CORRUPT (batch
+ * form: bit 63 of d_consumed[b]).  Off by default. */
+int rspt_hip_set_verify(rspt_hip_packer* p, int on);
+
 /* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
 
 /* Grow the workspace so that up to max_blocks blocks can go through one

@@ -21,7 +21,7 @@ KINDS = {"hzr": 0, "xdelta_hzr": 1, "dct": 2, "hadamard": 3}
 C_ABI_SYMBOLS = [
     "rspt_hip_status_string", "rspt_hip_last_hip_error", "rspt_hip_device_count", "rspt_hip_packer_create",
     "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
-    "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
+    "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read",
 ]
@@ -68,6 +68,7 @@ def lib():
     L.rspt_hip_block_bytes.restype, L.rspt_hip_block_bytes.argtypes = C.c_size_t, [C.c_void_p]
     L.rspt_hip_current_nb.restype, L.rspt_hip_current_nb.argtypes = C.c_uint, [C.c_void_p]
     L.rspt_hip_set_nb.restype, L.rspt_hip_set_nb.argtypes = C.c_int, [C.c_void_p, C.c_uint]
+    L.rspt_hip_set_verify.restype, L.rspt_hip_set_verify.argtypes = C.c_int, [C.c_void_p, C.c_int]
     L.rspt_hip_reserve.restype, L.rspt_hip_reserve.argtypes = C.c_int, [C.c_void_p, C.c_size_t]
     L.rspt_hip_compress_batch_dev.restype = C.c_int
     L.rspt_hip_compress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -150,6 +151,10 @@ class SignalPacker:
 
     def set_nb(self, nb):
         self._check("rspt_hip_set_nb", self._L.rspt_hip_set_nb(self._h, nb))
+
+    def set_verify(self, on=True):
+        """check every block's CRC-32C on decompress (hzr_verify's job in the reference); off by default"""
+        self._check("rspt_hip_set_verify", self._L.rspt_hip_set_verify(self._h, int(bool(on))))
 
     # -- device-resident batches (torch tensors carry the memory) --------------
     def reserve(self, nblocks):

@@ -219,7 +219,7 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
 __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
                                                           const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
                                                           uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
-                                                          unsigned long long* __restrict__ stamps) {
+                                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc) {
     __shared__ DecLds d;
     // workgroup -> hzr block, plane-major (grid.x = blocks * nblk, grid.y = plane): with the plane fastest the dense
     // plane-0 blocks would all land on the XCDs 0 and 4 (workgroup i goes to XCD i % 8)
@@ -251,6 +251,52 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // the bit window reads up to two words past the last payload word
     for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;  // (the tree parse below writes into it)
     __syncthreads();
+
+    if (vcc) {
+        // hzr_verify (hzr_decode.c:569-624): CRC-32C of the payload against the header.  Word-strided lanes over the
+        // staged payload as in the encoder (hzr_kernels.hip: encode_block), without the X prefix: crc = ~(raw(payload) ^
+        // 0xFFFFFFFF * x^(8 L)); the x^(8*4096) step table comes straight from global memory (this path is optional).
+        const uint32_t nvw = (L + 3u) >> 2;
+        const uint32_t Kst = (nvw + kDecThreads - 1) / kDecThreads;
+        const uint8_t* pb = reinterpret_cast<const uint8_t*>(d.stage) + skew;  // payload byte 0
+        auto vword = [&](uint32_t r) -> uint32_t {                             // payload bytes [L - 4(r+1), L - 4r), zero in front
+            const int32_t lo = (int32_t)L - 4 * (int32_t)(r + 1);
+            uint32_t v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v |= (lo + q >= 0 ? (uint32_t)pb[lo + q] : 0u) << (8 * q);
+            return v;
+        };
+        uint32_t c = 0;
+        if (tid < nvw) {
+            for (uint32_t kk = Kst - 1; kk >= 1; --kk) {
+                const uint32_t r = tid + kDecThreads * kk;
+                if (r < nvw) c ^= vword(r);
+                c = gf_shift(vcc, 78, c);  // * x^(8*4096)
+            }
+            c ^= vword(tid);
+            c = gf_shift4(vcc, l, c);  // to the end of the wave's 64 words
+        }
+        c = wave_xor_u32(c);
+        if (l == 0) d.wsum[w] = gf_shift(vcc, 63u - 4u * w, c);  // * x^(8*256*w): to the end of the payload
+        __syncthreads();
+        uint32_t bad_crc = 0;
+        if (tid == 0) {
+            uint32_t raw = 0;
+            for (uint32_t i = 0; i < kDecThreads / 64; ++i) raw ^= d.wsum[i];
+            // the initial state 0xFFFFFFFF travels through L bytes: 4096 a + 64 b + 4 c4 + dbytes
+            uint32_t init = 0xFFFFFFFFu;
+            const uint32_t a = L >> 12, bq = (L >> 6) & 63u, c4 = (L >> 2) & 15u, dbytes = L & 3u;
+            if (a) init = gf_shift(vcc, a == 16 ? 80u : 64u + (15u - a), init);  // x^(8*4096*a); a = 16 only for L = 65536
+            if (bq) init = gf_shift(vcc, 63u - bq, init);         // x^(8*64*bq)
+            if (c4) init = gf_shift4(vcc, c4 - 1u, init);         // x^(8*4*c4)
+            for (uint32_t q = 0; q < dbytes; ++q) init = vcc->table[0][init & 0xFFu] ^ (init >> 8);
+            bad_crc = (~(raw ^ init)) != ld_le32(s + 2) ? 1u : 0u;
+        }
+        if (__syncthreads_or((int)bad_crc)) {
+            if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+            return;
+        }
+    }
 
     if (mode == kModeCopy) {  // hzr_decode.c:351-359
         if (L != out_size) {

@@ -161,6 +161,7 @@ struct rspt_hip_packer {
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
+    int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
 
     // the small-block encoder runs beside the big one (it fills the CUs the persistent grid frees in its tail)
     hipStream_t side = nullptr;
@@ -722,6 +723,12 @@ int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb) {
     return RSPT_HIP_OK;
 }
 
+int rspt_hip_set_verify(rspt_hip_packer* p, int on) {
+    if (!p) return RSPT_HIP_ERR_ARG;
+    p->verify = on ? 1 : 0;
+    return RSPT_HIP_OK;
+}
+
 static int ensure_host_staging(rspt_hip_packer* p) {
     const size_t need_dst = rspt_hip_max_compressed_size(p) + 64;
     if (!p->h_src) {
@@ -778,7 +785,7 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
                            d_consumed, p->means);
         hipLaunchKernelGGL(k_dec_block, dim3(g.nblk * B, kMaxPlanes), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
-                           d_consumed, p->ablate ? p->stamps : nullptr);
+                           d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr);
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
         if (xd) {

@@ -129,3 +129,37 @@ def test_batched_decompress(api, orc):
         assert int(d_used[i]) == len(streams[i])
         assert d_out[i].cpu().numpy().tobytes() == blocks[i].tobytes()
     pk.close()
+
+
+def test_verify_checks_block_crcs(api, orc, packer_cases):
+    """rspt_hip_set_verify: what hzr_verify does in the reference (hzr_decode.c:569-624)"""
+    c = packer_cases["ecg12_i32"] if "ecg12_i32" in packer_cases else next(v for v in packer_cases.values() if v["kind"] == "xdelta_hzr" and v["nch"] * v["ns"] > 100000)
+    po = orc.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    stream = bytearray(po.compress(c["data"]))
+    pk = api.SignalPacker(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    pk.set_nb(orc.packer_nb(po))
+    pk.set_verify(True)
+    dec, used = pk.decompress(bytes(stream))  # a sound stream passes, every block size and alignment included
+    assert used == len(stream) and dec == c["data"].tobytes()
+    # flip one bit of a stored CRC (first hzr block of plane 0: stream[9..] = u16 len, u32 crc): decoding would not notice
+    bad = bytearray(stream)
+    bad[9 + 2] ^= 0x10
+    pk.set_verify(False)
+    dec2, used2 = pk.decompress(bytes(bad))
+    assert dec2 == c["data"].tobytes()
+    pk.set_verify(True)
+    with pytest.raises(api.RsptHipError):
+        pk.decompress(bytes(bad))
+    pk.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 63, 64, 65, 255, 4096, 4097, 65535, 65536, 70001])
+def test_verify_all_payload_lengths(api, orc, n):
+    """payload lengths around every boundary of the CRC's shift decomposition (incompressible data: PlainCopy, L = n)"""
+    data = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8)
+    pk = api.new_hzr(1, 1, n)
+    pk.set_verify(True)
+    got = pk.compress(data, dst_max_len=pk.max_compressed_size)
+    dec, used = pk.decompress(got)
+    assert used == len(got) and dec == data.tobytes()
+    pk.close()

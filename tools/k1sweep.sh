@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
-for cfg in "256 352" "256 384" "256 320" "256 256" "256 128" "512 352" "512 384"; do
+for cfg in "256 384" "320 384" "384 384" "512 384" "192 384"; do
   set -- $cfg
   RSPT_K1_THREADS=$1 RSPT_TILE=$2 timeout -k 10 100 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('threads=$1 tile=$2', d['value'], d['roofline']['kernel_ms']['preprocess'])" || exit 1
 done
