@@ -137,6 +137,11 @@ size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks);
 int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_stride, const uint64_t* d_sizes, size_t nblocks, void* d_packed,
                             uint64_t* d_total, void* stream);
 
+/* Decompress the nblocks streams of a container resident in device memory (16-byte aligned), as laid out above: the
+ * consumer side of the gather.  The container's nb field is NOT applied: read it from the header and call
+ * rspt_hip_set_nb first when the streams come from another instance.  d_consumed as in the batch form. */
+int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t nblocks, void* d_dst, uint64_t* d_consumed, void* stream);
+
 /* The handle's own (non-blocking) stream, as a hipStream_t. */
 void* rspt_hip_stream(rspt_hip_packer* p);
 

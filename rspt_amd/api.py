@@ -22,7 +22,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_status_string", "rspt_hip_last_hip_error", "rspt_hip_device_count", "rspt_hip_packer_create",
     "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
-    "rspt_hip_decompress_batch_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
+    "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read",
 ]
 
@@ -74,6 +74,8 @@ def lib():
     L.rspt_hip_compress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.rspt_hip_decompress_batch_dev.restype = C.c_int
     L.rspt_hip_decompress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rspt_hip_decompress_packed_dev.restype = C.c_int
+    L.rspt_hip_decompress_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rspt_hip_synchronize.restype, L.rspt_hip_synchronize.argtypes = C.c_int, [C.c_void_p]
     L.rspt_hip_stream.restype, L.rspt_hip_stream.argtypes = C.c_void_p, [C.c_void_p]
     L.rspt_hip_pack_bound.restype, L.rspt_hip_pack_bound.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t]
@@ -189,6 +191,26 @@ class SignalPacker:
         st = stream if stream is not None else torch.cuda.current_stream(d_streams.device).cuda_stream
         rc = self._L.rspt_hip_decompress_batch_dev(self._h, d_streams.data_ptr(), src_stride, nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
         self._check("rspt_hip_decompress_batch_dev", rc)
+        return d_out, d_consumed
+
+    def decompress_packed(self, d_packed, d_out=None, d_consumed=None, stream=None, apply_nb=True):
+        """Decompress every stream of a container (what pack_batch / the multi-GPU gather produce) on the device.
+        Reads the 32-byte header to the host for the block count and nb (a synchronisation)."""
+        import torch
+
+        head = d_packed[:32].cpu().numpy().view(np.uint64)
+        if int(head[0]) != 0x4B43415054505352:
+            raise ValueError("not an RSPTPACK container")
+        nblocks, nb = int(head[1]), int(head[3])
+        if apply_nb and self.kind == KINDS["xdelta_hzr"]:
+            self.set_nb(nb)
+        if d_out is None:
+            d_out = torch.empty((nblocks, self.block_bytes), dtype=torch.uint8, device=d_packed.device)
+        if d_consumed is None:
+            d_consumed = torch.empty(nblocks, dtype=torch.int64, device=d_packed.device)
+        st = stream if stream is not None else torch.cuda.current_stream(d_packed.device).cuda_stream
+        rc = self._L.rspt_hip_decompress_packed_dev(self._h, d_packed.data_ptr(), nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
+        self._check("rspt_hip_decompress_packed_dev", rc)
         return d_out, d_consumed
 
     def pack_bound(self, nblocks):

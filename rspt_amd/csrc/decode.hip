@@ -24,14 +24,28 @@ __device__ __forceinline__ uint32_t ld_le32(const uint8_t* p) {
 }
 
 // one thread per (block, plane)
-__global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride, uint32_t nblocks, Geom g, const uint32_t* __restrict__ nb_state,
-                            uint64_t* __restrict__ blk_off, uint64_t* __restrict__ consumed, uint8_t* __restrict__ means) {
+// Where stream b starts and how many bytes it may span: fixed stride, or the (offset, length) index of a container
+// (include/rspt_hip.h: 'RSPTPACK'; `src` then points at the container's payload).
+__device__ __forceinline__ const uint8_t* stream_base(const uint8_t* src, uint64_t src_stride, const uint64_t* __restrict__ pidx, uint32_t b,
+                                                     uint64_t& limit) {
+    if (pidx) {
+        limit = pidx[2 * b + 1];
+        return src + pidx[2 * b];
+    }
+    limit = src_stride;
+    return src + (size_t)b * src_stride;
+}
+
+__global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride_in, uint32_t nblocks, Geom g, const uint32_t* __restrict__ nb_state,
+                            uint64_t* __restrict__ blk_off, uint64_t* __restrict__ consumed, uint8_t* __restrict__ means,
+                            const uint64_t* __restrict__ pidx) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = t / kMaxPlanes, k = t % kMaxPlanes;
     if (b >= nblocks) return;
     const uint32_t nb = *nb_state;
     if (k >= nb) return;
-    const uint8_t* s = src + (size_t)b * src_stride;
+    uint64_t src_stride;  // bytes stream b may span
+    const uint8_t* s = stream_base(src, src_stride_in, pidx, b, src_stride);
     uint64_t pos = 1ull + g.hdr_len;
     bool bad = false;
     for (uint32_t kk = 0; kk < k; ++kk) {
@@ -219,7 +233,8 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
 __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
                                                           const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
                                                           uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
-                                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc) {
+                                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
+                                                          const uint64_t* __restrict__ pidx) {
     __shared__ DecLds d;
     // workgroup -> hzr block, plane-major (grid.x = blocks * nblk, grid.y = plane): with the plane fastest the dense
     // plane-0 blocks would all land on the XCDs 0 and 4 (workgroup i goes to XCD i % 8)
@@ -231,7 +246,8 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     DEC_STAMP(0);
     const uint64_t off = blk_off[hb];
     if (off == ~0ull) return;
-    const uint8_t* s = src + (size_t)b * src_stride + off;
+    uint64_t lim_unused;
+    const uint8_t* s = stream_base(src, src_stride, pidx, b, lim_unused) + off;
     const uint32_t L = ld_le16(s) + 1u;
     const uint32_t mode = s[6];
     const uint32_t out_size = min(kHzrBlock, g.N - j * kHzrBlock);

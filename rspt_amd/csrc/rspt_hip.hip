@@ -770,8 +770,23 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
     return RSPT_HIP_OK;
 }
 
+static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t nblocks, void* d_dst,
+                          uint64_t* d_consumed, void* stream);
+
 int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, size_t nblocks, void* d_dst, uint64_t* d_consumed,
                                   void* stream) {
+    return decompress_dev(p, d_src, src_stride, nullptr, nblocks, d_dst, d_consumed, stream);
+}
+
+int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t nblocks, void* d_dst, uint64_t* d_consumed, void* stream) {
+    if (!d_packed || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return RSPT_HIP_ERR_ARG;
+    const uint8_t* base = (const uint8_t*)d_packed;
+    // header 32 bytes, index 16 bytes per stream, then the payload the offsets are relative to
+    return decompress_dev(p, base + 32 + 16 * nblocks, 0, reinterpret_cast<const uint64_t*>(base + 32), nblocks, d_dst, d_consumed, stream);
+}
+
+static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t nblocks, void* d_dst,
+                          uint64_t* d_consumed, void* stream) {
     if (!p || !d_src || !d_dst || !d_consumed || nblocks == 0) return RSPT_HIP_ERR_ARG;
     int rc = rspt_hip_reserve(p, nblocks);
     if (rc) return rc;
@@ -783,9 +798,9 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
         const uint8_t* src = (const uint8_t*)d_src;
         HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
-                           d_consumed, p->means);
+                           d_consumed, p->means, pidx);
         hipLaunchKernelGGL(k_dec_block, dim3(g.nblk * B, kMaxPlanes), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
-                           d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr);
+                           d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr, pidx);
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
         if (xd) {

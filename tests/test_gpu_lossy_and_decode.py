@@ -163,3 +163,27 @@ def test_verify_all_payload_lengths(api, orc, n):
     dec, used = pk.decompress(got)
     assert used == len(got) and dec == data.tobytes()
     pk.close()
+
+
+def test_decompress_straight_from_a_container(api, orc):
+    """pack_batch -> decompress_packed: the consumer side of the multi-GPU gather, no host hop for the payload"""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns, B = 12, 8192, 5
+    d_src = synth.synth_batch_native(B, nch, ns, first_block=40, device="cuda")
+    pk = api.new_xdelta_hzr(4, nch, ns, 2)
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    d_dst = torch.empty((B, stride), dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(B, dtype=torch.int64, device="cuda")
+    pk.compress_batch(d_src, d_dst, d_sizes, stride)
+    packed, total = pk.pack_batch(d_dst, d_sizes)
+    torch.cuda.synchronize()
+    other = api.new_xdelta_hzr(4, nch, ns, 1)  # another instance: nb comes from the container
+    out, used = other.decompress_packed(packed[: int(total.item())])
+    torch.cuda.synchronize()
+    assert torch.equal(out, d_src) and torch.equal(used, d_sizes)
+    assert other.nb == pk.nb
+    pk.close()
+    other.close()
