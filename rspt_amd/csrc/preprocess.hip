@@ -352,6 +352,38 @@ template <bool XDELTA>
 __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict__ planar, Geom g, uint32_t nplanes,
                                                        uint8_t* __restrict__ planes, uint32_t* __restrict__ nzflag) {
     const uint32_t b = blockIdx.y;
+    if (!XDELTA) {
+        // No neighbour dependence: fully coalesced form.  A wave takes 1024 consecutive elements (one KiB of every plane);
+        // in each of four rounds lane l loads elements [256 q + 4 l, +4) as 16 bytes and stores one dword per plane.
+        const uint32_t wbase = (blockIdx.x * 256 + (threadIdx.x & ~63u)) * 16;  // first element of this wave
+        const int32_t* pw_ = planar + (size_t)b * g.N;
+        if (wbase + 1024 <= g.N && (reinterpret_cast<uintptr_t>(pw_ + wbase) & 15u) == 0) {
+            const uint32_t l = threadIdx.x & 63u;
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4*>(pw_ + wbase)[q * 64 + l];
+            uint32_t nzk[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t a0 = v[q].x, a1 = v[q].y, a2 = v[q].z, a3 = v[q].w;
+                const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+                const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+                const uint32_t pl[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
+                                        __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    if (k < nplanes) {
+                        reinterpret_cast<uint32_t*>(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + wbase)[q * 64 + l] = pl[k];
+                        nzk[k] |= pl[k];
+                    }
+                }
+            }
+            for (uint32_t k = 0; k < nplanes; ++k) {
+                if (__ballot(nzk[k] != 0) && l == 0) atomicOr(&nzflag[hb_index(g, b, k, wbase >> 16)], 1u << ((wbase >> 12) & 15u));
+            }
+            return;
+        }
+    }
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 16;
     if (i0 >= g.N) return;  // (a wave's 1024 elements never straddle a 64 KiB hzr block)
     const int32_t* p = planar + (size_t)b * g.N;
@@ -363,10 +395,25 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
         oprev = p1 - p2 - 128u;
     }
     uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint32_t xs[16];
+    if (cnt == 16 && (reinterpret_cast<uintptr_t>(p + i0) & 15u) == 0) {  // four 16-byte loads instead of sixteen dword loads at a 64-byte lane stride
+        const uint4* p4 = reinterpret_cast<const uint4*>(p + i0);
+#pragma unroll
+        for (uint32_t q4 = 0; q4 < 4; ++q4) {
+            const uint4 v4 = p4[q4];
+            xs[4 * q4] = v4.x;
+            xs[4 * q4 + 1] = v4.y;
+            xs[4 * q4 + 2] = v4.z;
+            xs[4 * q4 + 3] = v4.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) xs[e] = e < cnt ? (uint32_t)p[i0 + e] : 0u;
+    }
 #pragma unroll
     for (uint32_t e = 0; e < 16; ++e) {
         if (e < cnt) {
-            uint32_t x = (uint32_t)p[i0 + e];
+            uint32_t x = xs[e];
             uint32_t v = x;
             if (XDELTA) {
                 uint32_t o = x - p1 - 128u;

@@ -92,11 +92,38 @@ __global__ __launch_bounds__(1024) void k_fwht(int32_t* __restrict__ planar, Geo
 #pragma unroll
             for (int jj = 0; jj < 32; ++jj) row[tid + 1024u * jj] = keep[jj];
         }
-        for (uint32_t w = hn >> 1; w >= 1; w >>= 1) {
+        // (lo,hi) -> (lo+hi, lo-hi) per stage (fwht.c:19-22); the stages commute exactly in wrap-around arithmetic, so
+        // three of them are taken at a time on eight values held in registers: a third of the LDS traffic and barriers
+        uint32_t w = hn >> 1;
+        while (w >= 4) {  // stages w, w/2, w/4 together: elements base + {0..7} * (w/4)
+            const uint32_t st = w >> 2;
+            for (uint32_t q = tid; q < (hn >> 3); q += 1024) {
+                const uint32_t base = ((q & ~(st - 1)) << 3) | (q & (st - 1));
+                uint32_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (uint32_t)sh[base + i * st];
+#pragma unroll
+                for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (!(i & d)) {
+                            const uint32_t x = v[i], y = v[i + d];
+                            v[i] = x + y;
+                            v[i + d] = x - y;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sh[base + i * st] = (int32_t)v[i];
+            }
+            __syncthreads();
+            w >>= 3;
+        }
+        for (; w >= 1; w >>= 1) {  // the one or two stages left
             for (uint32_t q = tid; q < (hn >> 1); q += 1024) {
                 const uint32_t lo = ((q & ~(w - 1)) << 1) | (q & (w - 1));
                 const uint32_t x = (uint32_t)sh[lo], y = (uint32_t)sh[lo + w];
-                sh[lo] = (int32_t)(x + y);  // (lo,hi) -> (lo+hi, lo-hi), fwht.c:19-22
+                sh[lo] = (int32_t)(x + y);
                 sh[lo + w] = (int32_t)(x - y);
             }
             __syncthreads();
