@@ -468,6 +468,49 @@ __global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__
     }
 }
 
+// The common shape of the same conversion -- int32 samples, nch % 4 == 0, ns % 4 == 0, 16-byte aligned input -- with 16-byte
+// global accesses on both sides and no division per element (the mirror image of decode.hip: k_planar_native_i32x4).
+__global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __restrict__ src, Geom g, uint32_t T4, int32_t* __restrict__ planar) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    int32_t* tile = reinterpret_cast<int32_t*>(lds);  // [nch][T4+1]
+    const uint32_t tid = threadIdx.x, b = blockIdx.y;
+    const uint32_t s0 = blockIdx.x * T4;
+    const uint32_t Tn = min(T4, g.ns - s0);  // a multiple of 4
+    const uint32_t RS = T4 + 1;
+    {
+        const uint32_t cpr = g.nch >> 2;  // 16-byte pieces per sample row
+        const uint32_t step_t = 256u / cpr, step_c = 256u - step_t * cpr;
+        uint32_t t = tid / cpr, c4 = tid - t * cpr;
+        const int4* in = reinterpret_cast<const int4*>(src + (size_t)b * g.block_bytes + (size_t)s0 * g.nch * 4u);
+        for (uint32_t u = tid; u < Tn * cpr; u += 256) {
+            const int4 v = in[u];
+            int32_t* r = tile + (4u * c4) * RS + t;
+            r[0] = v.x;
+            r[RS] = v.y;
+            r[2 * RS] = v.z;
+            r[3 * RS] = v.w;
+            c4 += step_c;
+            const uint32_t carry = c4 >= cpr ? 1u : 0u;
+            c4 -= carry ? cpr : 0u;
+            t += step_t + carry;
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t qpr = Tn >> 2;  // 16-byte pieces per channel row
+        const uint32_t step_c = 256u / qpr, step_t = 256u - step_c * qpr;
+        uint32_t c = tid / qpr, t4 = tid - c * qpr;
+        for (uint32_t u = tid; u < g.nch * qpr; u += 256) {
+            const int32_t* r = tile + c * RS + 4u * t4;
+            *reinterpret_cast<int4*>(planar + (size_t)b * g.N + (size_t)c * g.ns + s0 + 4u * t4) = make_int4(r[0], r[1], r[2], r[3]);
+            t4 += step_t;
+            const uint32_t carry = t4 >= qpr ? 1u : 0u;
+            t4 -= carry ? qpr : 0u;
+            c += step_c + carry;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // nb bookkeeping (signal_packer_xdelta_hzr.cpp:63-69): nb used by block b =
 // max(nb carried in, need(0..b)); the last value is carried to the next call.

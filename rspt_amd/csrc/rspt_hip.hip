@@ -215,6 +215,14 @@ static uint32_t launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nb
         launch_planes<BPS, false>(p, d_src, nblocks, 0, 4, nullptr, st);
         return 4;
     }
+    if (BPS == 4 && (g.nch & 3) == 0 && (g.ns & 3) == 0 && g.nch <= 1024 && (reinterpret_cast<uintptr_t>(d_src) & 15) == 0) {
+        uint32_t T4 = (uint32_t)((32768ull / (4ull * g.nch) - 1) & ~3ull);  // T4 samples x nch channels in at most 32 KiB of LDS
+        T4 = T4 > 1024 ? 1024 : T4 < 4 ? 4 : T4;
+        if (T4 > g.ns) T4 = g.ns;
+        hipLaunchKernelGGL(k_tile_planar_i32x4, dim3((g.ns + T4 - 1) / T4, (unsigned)nblocks), dim3(256), g.nch * (T4 + 1) * 4, st, d_src, g, T4,
+                           p->planar);
+        return 4;
+    }
     dim3 grid((g.ns + p->T - 1) / p->T, (unsigned)nblocks);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planar<BPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->in_lds);
     hipLaunchKernelGGL((k_tile_planar<BPS>), grid, dim3(256), p->in_lds, st, d_src, g, p->T, p->planar);
