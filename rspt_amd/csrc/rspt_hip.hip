@@ -236,7 +236,8 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
     const Geom& g = p->g;
     const uint32_t l1 = p->fft_l1, l2 = p->fft_l2;
     const uint32_t lw = std::min(kFftLdsLog - l1, l2), lr = std::min(kFftLdsLog - l2, l1);
-    const uint32_t lds_c = (uint32_t)sizeof(double2) << (l1 + lw), lds_r = (uint32_t)sizeof(double2) << (l2 + lr);
+    const uint32_t lds_c = ((uint32_t)sizeof(double2) << (l1 + lw)) + ((uint32_t)sizeof(double2) << (l1 - 1)),
+                   lds_r = ((uint32_t)sizeof(double2) << (l2 + lr)) + ((uint32_t)sizeof(double2) << (l2 - 1));  // points + stage twiddles
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_cols<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_rows<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {

@@ -256,8 +256,10 @@ __global__ __launch_bounds__(1024) void k_row_means(const int32_t* __restrict__ 
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return __brev(v) >> (32u - bits); }
 
-// radix-2 DIT over `len = 1<<logn` points of W = 1<<lw interleaved sequences: point p of sequence q at sh[p*W + q]
-__device__ __forceinline__ void lds_fft(double2* sh, uint32_t logn, uint32_t lw, const double2* __restrict__ tw, uint32_t nlog, bool inverse) {
+// radix-2 DIT over `len = 1<<logn` points of W = 1<<lw interleaved sequences: point p of sequence q at sh[p*W + q].
+// stw[m] = (cos, sin)(2 pi m / len), m < len/2: the stage twiddles, staged in LDS by the caller (the butterflies would
+// otherwise wait on a global load each).
+__device__ __forceinline__ void lds_fft(double2* sh, const double2* stw, uint32_t logn, uint32_t lw, bool inverse) {
     const uint32_t W = 1u << lw;
     const uint32_t nbf = (1u << (logn - 1)) << lw;
     for (uint32_t s = 1; s <= logn; ++s) {
@@ -266,7 +268,7 @@ __device__ __forceinline__ void lds_fft(double2* sh, uint32_t logn, uint32_t lw,
             const uint32_t col = q & (W - 1), bf = q >> lw;
             const uint32_t m = bf & (half - 1);
             const uint32_t i0 = ((bf >> (s - 1)) << s) + m;
-            const double2 w = tw[(size_t)m << (nlog - s)];
+            const double2 w = stw[m << (logn - s)];
             const double ws = inverse ? w.y : -w.y;
             const double2 a = sh[i0 * W + col], bq = sh[(i0 + half) * W + col];
             const double tr = bq.x * w.x - bq.y * ws, ti = bq.x * ws + bq.y * w.x;
@@ -275,6 +277,11 @@ __device__ __forceinline__ void lds_fft(double2* sh, uint32_t logn, uint32_t lw,
         }
         __syncthreads();
     }
+}
+
+// stage twiddle table of an FFT of length 1 << logn out of the n-point table (n = 1 << nlog)
+__device__ __forceinline__ void load_stage_twiddles(double2* stw, const double2* __restrict__ tw, uint32_t logn, uint32_t nlog) {
+    for (uint32_t m = threadIdx.x; m < (1u << (logn - 1)); m += blockDim.x) stw[m] = tw[(size_t)m << (nlog - logn)];
 }
 
 constexpr uint32_t kFftLdsLog = 12;  // 4096 complex fp64 points (64 KiB) per workgroup
@@ -289,6 +296,8 @@ __global__ __launch_bounds__(256) void k_dctfft_cols(const int32_t* __restrict__
     const uint32_t j2_0 = blockIdx.x << lw, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
     const int32_t* row = in + (size_t)b * g.N + (size_t)c * n;
     const uint32_t total = 1u << (l1 + lw);
+    double2* stw = shf + total;  // (the launcher sizes the dynamic LDS for both)
+    load_stage_twiddles(stw, tw, l1, nlog);
     const int32_t mean = FORWARD ? mean_i32[(size_t)b * g.nch + c] : 0;
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const uint32_t col = idx & (W - 1), j1 = idx >> lw;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(256) void k_dctfft_cols(const int32_t* __restrict__
         shf[bitrev(j1, l1) * W + col] = v;
     }
     __syncthreads();
-    lds_fft(shf, l1, lw, tw, nlog, !FORWARD);
+    lds_fft(shf, stw, l1, lw, !FORWARD);
     double2* dst = scratch + ((size_t)bl * g.nch + c) * n;
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const uint32_t col = idx & (W - 1), k1 = idx >> lw;
@@ -337,13 +346,15 @@ __global__ __launch_bounds__(256) void k_dctfft_rows(const double2* __restrict__
     const uint32_t lr = min(kFftLdsLog - l2, l1), R = 1u << lr;
     const uint32_t k1_0 = blockIdx.x << lr, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
     const uint32_t total = 1u << (l2 + lr);
+    double2* stw = shf + total;
+    load_stage_twiddles(stw, tw, l2, nlog);
     const double2* src = scratch + ((size_t)bl * g.nch + c) * n + ((size_t)k1_0 << l2);
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const uint32_t r = idx >> l2, j2 = idx & (n2 - 1);
         shf[bitrev(j2, l2) * R + r] = src[idx];
     }
     __syncthreads();
-    lds_fft(shf, l2, lr, tw, nlog, !FORWARD);
+    lds_fft(shf, stw, l2, lr, !FORWARD);
     int32_t* orow = out + (size_t)b * g.N + (size_t)c * n;
     const int32_t mean = FORWARD ? 0 : load_mean_hdr(means, g, b, c);
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
