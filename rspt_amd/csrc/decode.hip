@@ -604,13 +604,26 @@ __global__ __launch_bounds__(256) void k_inv_tile(const uint8_t* __restrict__ pl
 #pragma unroll
         for (int e = 0; e < 16; ++e) p[e] = v[e];
     }
-    int32_t* dstp = planar + (size_t)b * g.N + i0;
-    if (cnt == 16) {
+    // Each thread holds 16 consecutive results: stored directly, a wave would write 16-byte pieces 64 bytes apart.  Whole
+    // tiles go through LDS instead (rows of 17 words: conflict-free both ways) and leave as 1 KiB per wave-store.
+    __shared__ uint32_t s_t[256 * 17];
+    const uint32_t tile0 = tile * kInvTile;
+    const bool whole = tile0 + kInvTile <= g.N && (((size_t)b * g.N + tile0) & 3u) == 0;  // (block-uniform)
+    if (whole) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<uint4*>(dstp)[q] = make_uint4(p[4 * q], p[4 * q + 1], p[4 * q + 2], p[4 * q + 3]);
-    } else {
-        for (uint32_t e = 0; e < cnt; ++e) dstp[e] = (int32_t)p[e];
+        for (int e = 0; e < 16; ++e) s_t[tid * 17 + e] = p[e];
+        __syncthreads();
+        uint4* o4 = reinterpret_cast<uint4*>(planar + (size_t)b * g.N + tile0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t j = 4u * (tid + 256u * q);  // element of the tile
+            const uint32_t* r = s_t + (j >> 4) * 17 + (j & 15u);
+            o4[tid + 256u * q] = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        return;
     }
+    int32_t* dstp = planar + (size_t)b * g.N + i0;
+    for (uint32_t e = 0; e < cnt; ++e) dstp[e] = (int32_t)p[e];
 }
 
 // exclusive scan of the per-tile totals of one block, in place (one workgroup per block)
