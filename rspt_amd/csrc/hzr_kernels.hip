@@ -3,16 +3,20 @@
 // lib_hzr/hzr_encode.c; the parallel formulations are modelled and checked on
 // the CPU in tools/kernel_model.py + tests/test_kernel_model.py.
 //
-//   k_hist    one 1024-thread workgroup per hzr block: zero-run tokenizer
-//             (hzr_encode.c:133-173) on 16-byte granules + 261-bin histogram
+//   k_hist    persistent 1024-thread workgroups, one hzr block at a time: zero-run tokenizer
+//             (hzr_encode.c:133-173) on 16-byte granules; per-wave 261-bin histograms -> block histogram,
+//             per-segment histograms and the zero-run context of every granule (for k_tree / k_encode)
 //   k_tree    one wave per hzr block: Fill test (:285-305), Huffman tree with
 //             the reference's tie-break (:222-283), codes + pre-order tree
-//             description (:177-219), exact payload size -> block mode (:377-469)
+//             description (:177-219), exact payload size -> block mode (:377-469),
+//             stream bit at which each 4 KiB segment's tokens start
 //   k_layout  one workgroup per block: sizes -> stream offsets, stream framing
-//             (signal_packer_base.cpp:69-95, hzr_encode.c:521-522)
-//   k_encode  one 1024-thread workgroup per hzr block: emit codes into an LDS
-//             image of the payload (:410-457), parallel CRC-32C
+//             (signal_packer_base.cpp:69-95, hzr_encode.c:521-522), work queues
+//   k_encode  persistent 1024-thread workgroups, one big hzr block at a time: one pass from
+//             lookup to an LDS image of the payload (:410-457), parallel CRC-32C
 //             (hzr_crc32c.c:77-84), block header (:475-481), coalesced copy-out
+//   k_encode_small   one wave per small hzr block (few non-zero segments, tokens, payload bytes)
+//   k_pack_*  the streams of a batch as one container (rspt_hip_pack_batch_dev)
 #include "common.hpp"
 
 namespace rspt {
@@ -780,7 +784,6 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
 // byte 4: the image IS the virtual CRC input V = X || payload.  Both access patterns are bank-conflict free without
 // padding: consecutive words by consecutive lanes (emit, copy-out), and the CRC reads word-strided -- lane tid owns
 // the virtual words tid, tid + 1024, ... counted from the END of V (tools/kernel_model.py:crc_strided).
-__device__ __forceinline__ uint32_t skew(uint32_t w) { return w; }  // (kept as the one place that maps a logical word to LDS)
 constexpr uint32_t kStageWords = kHzrBlock / 4 + 32;  // X + payload + read slack
 constexpr uint32_t kStagePhys = kStageWords + 2;
 
@@ -799,34 +802,6 @@ struct EncLds {
     uint32_t crc_out;
     uint32_t runcls[kRunClsEntries];  // zero-run length -> symbol | extra bits << 12 | first length of the class << 16
     uint32_t stage[kStagePhys];
-};
-
-struct BitSink {
-    uint32_t* stage;
-    uint32_t lo;    // partial word being assembled (bits below n)
-    uint32_t n;     // bits held in lo (< 32 between calls)
-    uint32_t word;  // next logical staging word
-    __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
-        stage = s;
-        lo = 0;
-        n = bitpos & 31u;
-        word = bitpos >> 5;
-    }
-    __device__ __forceinline__ void put(uint32_t v, uint32_t len) {  // len <= 32, v has no bits above len
-        lo |= v << n;
-        const uint32_t tot = n + len;
-        if (tot >= 32) {
-            atomicOr(&stage[skew(word)], lo);
-            ++word;
-            lo = (v >> 1) >> (31u - n);  // the bits of v that did not fit (v >> (32-n), defined for n = 0)
-            n = tot - 32;
-        } else {
-            n = tot;
-        }
-    }
-    __device__ __forceinline__ void flush() {
-        if (n) atomicOr(&stage[skew(word)], lo);
-    }
 };
 
 // pass 1: number of stream bits of the tokens that start in this granule
@@ -855,23 +830,14 @@ __device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint3
     return nb;
 }
 
-// OR `len` (<= 32) bits of v into the image at bit `pos`
-__device__ __forceinline__ void or_bits32(uint32_t* stage, uint32_t& pos, uint32_t v, uint32_t len) {
-    const uint32_t word = pos >> 5, sh = pos & 31u;
-    const uint64_t sv = (uint64_t)v << sh;
-    atomicOr(&stage[skew(word)], (uint32_t)sv);
-    if (sh + len > 32) atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
-    pos += len;
-}
-
 // OR up to 64 bits (hi:lo) into the image at bit `pos`: three words, unconditionally (zeros are harmless and
 // with 64 lanes some lane needs each of them anyway)
 __device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi) {
     const uint32_t word = pos >> 5, sh = pos & 31u;
     const uint64_t sv = (((uint64_t)hi << 32) | lo) << sh;
-    atomicOr(&stage[skew(word)], (uint32_t)sv);
-    atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
-    atomicOr(&stage[skew(word + 2)], (hi >> 1) >> (31u - sh));
+    atomicOr(&stage[word], (uint32_t)sv);
+    atomicOr(&stage[(word + 1)], (uint32_t)(sv >> 32));
+    atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
 }
 
 // The token that starts at byte i of a granule as one bit string: code, then the run's extra bits
@@ -897,9 +863,9 @@ __device__ __forceinline__ void token_at(uint32_t i, const GranuleMasks& m, uint
 __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t len) {
     const uint32_t word = pos >> 5, sh = pos & 31u;
     const uint64_t sv = (((uint64_t)hi << 32) | lo) << sh;
-    atomicOr(&stage[skew(word)], (uint32_t)sv);
-    atomicOr(&stage[skew(word + 1)], (uint32_t)(sv >> 32));
-    if (sh + len > 64) atomicOr(&stage[skew(word + 2)], (hi >> 1) >> (31u - sh));
+    atomicOr(&stage[word], (uint32_t)sv);
+    atomicOr(&stage[(word + 1)], (uint32_t)(sv >> 32));
+    if (sh + len > 64) atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
 }
 
 // One row (a granule per lane, 1 KiB per wave) from lookup to image in a single pass (hzr_encode.c:410-457).
@@ -914,7 +880,7 @@ __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t
 constexpr int kRowSlots = 8;
 constexpr uint32_t kTokQueue = 256;          // tokens per wave and row in the queue of a light block
 constexpr uint32_t kLightPayload = 16384;    // bytes: below it the image words from kTokQueueBase on are free
-constexpr uint32_t kTokQueueBase = 9000;     // physical stage word (> skew((16384 + 4) / 4 + 24))
+constexpr uint32_t kTokQueueBase = 9000;     // stage word (> (16384 + 4) / 4 + 24)
 
 __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
                                          const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t* stage, uint32_t& base, uint32_t* tokq) {
@@ -1052,7 +1018,7 @@ __device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, 
 }
 
 // byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
-__device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[skew(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }
+__device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }
 
 // `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
 // emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
@@ -1122,7 +1088,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
 
     if (m.mode == kModeHuff) {
         // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
-        const uint32_t zwords = skew(((L + 4) >> 2) + 24);
+        const uint32_t zwords = (((L + 4) >> 2) + 24);
         for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
         if (tid < kSymStride) d.cw[tid] = cw[(size_t)hb * kSymStride + tid];
         LaneBlock B;
@@ -1137,7 +1103,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         if (ablate & 32u) return;
         RSPT_STAMP(1);
         const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
-        if (tid < twords) atomicOr(&d.stage[skew(1 + tid)], tdesc[(size_t)hb * kTdescWords + tid]);
+        if (tid < twords) atomicOr(&d.stage[(1 + tid)], tdesc[(size_t)hb * kTdescWords + tid]);
         const bool active = wave_may_have_tokens(segmask, B);  // wave-uniform
         GranuleRegs q0 = granule_regs(B, 0), q1 = granule_regs(B, 1), q2 = granule_regs(B, 2), q3 = granule_regs(B, 3);
         if (first_base == 0xFFFFFFFFu) {
@@ -1176,10 +1142,10 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         for (uint32_t gi = tid; gi < kStageWords / 4 - 1; gi += kEncThreads) {
             uint4 v = make_uint4(0, 0, 0, 0);
             if (gi * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)gi * 16);
-            d.stage[skew(1 + gi * 4)] = v.x;
-            d.stage[skew(2 + gi * 4)] = v.y;
-            d.stage[skew(3 + gi * 4)] = v.z;
-            d.stage[skew(4 + gi * 4)] = v.w;
+            d.stage[(1 + gi * 4)] = v.x;
+            d.stage[(2 + gi * 4)] = v.y;
+            d.stage[(3 + gi * 4)] = v.z;
+            d.stage[(4 + gi * 4)] = v.w;
         }
     }
     if (tid == 0) d.stage[0] = cc->prefix;  // X (after this thread's own zeroing of word 0)
@@ -1246,7 +1212,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
     if (ablate & 8u) return;
     for (uint32_t i = tid; i < nd; i += kEncThreads) {
         // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
-        pw[i] = __builtin_amdgcn_alignbyte(d.stage[skew(i + 2)], d.stage[skew(i + 1)], head);
+        pw[i] = __builtin_amdgcn_alignbyte(d.stage[(i + 2)], d.stage[(i + 1)], head);
     }
     RSPT_STAMP(7);
     if ((ablate & 256u) && threadIdx.x == 0 && hb < 16384u) stamps[65536u + 2u * hb + 1u] = __builtin_amdgcn_s_memrealtime();
@@ -1264,7 +1230,7 @@ constexpr uint32_t kSlotWords = 1090;  // per-wave LDS slot of the small-block e
 constexpr uint32_t kSlotImage = kSlotWords - kSymStride;  // words of X || payload (+ slack)
 static_assert(kSlotImage * 4 >= kSmallPayload + 4 + 72, "small-block slot too small");
 
-struct LinSink {  // BitSink on a linear (unskewed) image
+struct LinSink {  // bit sink of the one-wave encoder: a 32-bit partial word, whole words stored to the wave's image
     uint32_t* img;
     uint32_t lo, n, word;
     __device__ __forceinline__ void start(uint32_t* s, uint32_t bitpos) {
