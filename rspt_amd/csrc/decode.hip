@@ -3,15 +3,16 @@
 //   k_dec_frame    walk the stream framing (signal_packer_base.cpp:98-119,
 //                  hzr_decode.c:626-674): plane chunk lengths, hzr block headers
 //                  -> per-block input offsets, consumed length, means header
-//   k_dec_block    one wave per hzr block (hzr_decode.c:335-567): copy / fill /
-//                  Huffman+RLE with a 10-bit LUT (the reference uses 8 bits) and a
-//                  tree walk for longer codes.  CRC is not checked, as in the
-//                  reference's decoder (hzr_decode.c:343).
+//   k_dec_block    one 1024-thread workgroup per hzr block (hzr_decode.c:335-567): copy / fill /
+//                  Huffman+RLE with a 10-bit LUT (the reference uses 8 bits) and a node walk for
+//                  longer codes; the code bits are decoded in up to 1024 self-synchronising chunks.
+//                  CRCs are checked only on request (rspt_hip_set_verify), as hzr_verify does;
+//                  the reference's decoder skips them too (hzr_decode.c:343).
 //   k_inv_*        planes -> int32 with sign extension from nb bytes
 //                  (signal_packer_base.cpp:121-138), then the inverse xdelta:
 //                  inclusive XOR scan, +128, inclusive sum (utils.cpp:204-236)
 //                  as a three-pass tiled scan over the flat array
-//   k_planar_native   [nch][ns] int32 -> interleaved native (utils.cpp:51-121)
+//   k_planar_native   [nch][ns] int32 -> interleaved native (utils.cpp:51-121); k_planar_native_i32x4: the int32 fast path
 #include "common.hpp"
 
 namespace rspt {
