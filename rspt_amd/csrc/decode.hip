@@ -113,12 +113,12 @@ constexpr uint32_t kNodeSlots = 528;
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
     uint32_t lut[1u << kLutBits];        // code of <= 10 bits: sym | len<<9;  longer: kLutLong | node reached after 10 bits
+    uint32_t cend[kDecThreads];          // first code boundary past a chunk's end  (lut + cend: 8 KiB of scratch for the tree parse)
     uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
     uint32_t leaf_code[kSymStride];
     uint16_t leaf_meta[kSymStride];  // sym | len<<9
-    uint32_t cend[kDecThreads];  // first code boundary past a chunk's end
     uint32_t wsum[kDecThreads / 64];
-    uint32_t nleaf, nnode;
+    uint32_t nleaf, nnode, endpos;
     uint32_t err;
     uint32_t changed;
     uint32_t code0;  // first bit of the codes
@@ -266,7 +266,6 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     for (uint32_t o = tid * 16; o < skew + L; o += kDecThreads * 16)
         *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
     if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // the bit window reads up to two words past the last payload word
-    for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;  // (the tree parse below writes into it)
     __syncthreads();
 
     if (vcc) {
@@ -343,57 +342,112 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     //     fewer is open than after the branch itself -- and so its child_b; parent links follow
     //   C (a thread per node): walk up to the root for depth and code; leaves fill the tables, branches at depth 10 mark
     //     where codes longer than the table index continue
-    uint16_t* t_open = reinterpret_cast<uint16_t*>(d.cend);  // (the chunk array is not in use yet)
+    // A, in parallel too: position p of the description starts a token iff it is reached from position 0 by the jumps
+    // p -> p + (bit p ? 10 : 1).  Pointer doubling marks every reached position in ten rounds (<= 521 tokens); one block
+    // scan over the marks numbers the nodes and counts the leaves, and the subtrees still open after a node follow from the
+    // two counts (1 + branches - leaves), so the first node that leaves none open ends the tree.
+    constexpr uint32_t kMaxDesc = 11u * kNumSym + 16u;  // description bits (11 S - 1) and a little slack
+    uint16_t* jump = reinterpret_cast<uint16_t*>(d.lut);                    // [kMaxDesc + 1]
+    uint32_t* mark = d.lut + (kMaxDesc + 2) / 2 + 1;                        // bit per position
+    static_assert(((kMaxDesc + 2) / 2 + 1 + kMaxDesc / 32 + 2) * 4 <= sizeof(d.lut) + sizeof(d.cend), "token-cut scratch does not fit");
+    const uint32_t P = min(kMaxDesc, bit_end - bit0);
+    auto dbit = [&](uint32_t p) -> uint32_t { return (d.stage[(bit0 + p) >> 5] >> ((bit0 + p) & 31u)) & 1u; };
+    for (uint32_t pz = tid; pz < kMaxDesc / 32 + 2; pz += kDecThreads) mark[pz] = pz == 0 ? 1u : 0u;  // position 0 is reached
+    for (uint32_t pp = tid; pp <= P; pp += kDecThreads) jump[pp] = (uint16_t)(pp < P ? min(P, pp + (dbit(pp) ? 10u : 1u)) : P);
+    if (tid == 0) {
+        d.err = 0;
+        d.endpos = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (uint32_t round = 0; round < 10; ++round) {
+        uint32_t j1[3], j2[3];
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q) {
+            const uint32_t pp = tid + q * kDecThreads;
+            j1[q] = pp <= P ? jump[pp] : P;
+            j2[q] = jump[j1[q]];
+            if (pp < P && ((mark[pp >> 5] >> (pp & 31u)) & 1u) && j1[q] < P) atomicOr(&mark[j1[q] >> 5], 1u << (j1[q] & 31u));
+        }
+        __syncthreads();  // every jump has been read, every mark of this round is set
+#pragma unroll
+        for (uint32_t q = 0; q < 3; ++q) {
+            const uint32_t pp = tid + q * kDecThreads;
+            if (pp <= P) jump[pp] = (uint16_t)j2[q];
+        }
+        __syncthreads();
+    }
+    // nodes in position order: thread t owns positions [3t, 3t+3)
+    uint32_t mine_n = 0, mine_l = 0, isnode[3], isleaf[3];
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        const uint32_t pp = 3u * tid + q;
+        isnode[q] = pp < P ? (mark[pp >> 5] >> (pp & 31u)) & 1u : 0u;
+        isleaf[q] = isnode[q] ? dbit(pp) : 0u;
+        mine_n += isnode[q];
+        mine_l += isleaf[q];
+    }
+    const uint32_t packed = mine_n | (mine_l << 16);
+    const uint32_t tincl = wave_scan_add(packed);
+    if (l == 63) d.wsum[w] = tincl;
+    __syncthreads();
+    uint32_t tpre = 0;
+    for (uint32_t i = 0; i < w; ++i) tpre += d.wsum[i];
+    uint32_t run = tpre + tincl - packed;  // nodes | leaves << 16 before this thread's positions
+    // (the marks and jumps are dead from here on: the node arrays may overwrite them -- but only after everybody has
+    //  read its marks, which the barrier above guarantees)
+    uint16_t* t_open = reinterpret_cast<uint16_t*>(d.cend);  // [kNodeSlots]  subtrees still open after the node
     uint16_t* t_par = t_open + kNodeSlots;                     // parent | child_b? << 15
     uint16_t* t_ord = t_par + kNodeSlots;                      // leaf ordinal
     static_assert(3 * kNodeSlots * sizeof(uint16_t) <= sizeof(d.cend), "tree scratch does not fit");
-    if (tid == 0) {
-        uint32_t bp = bit0, nn = 0, nleaf = 0, err = 0, open = 1;
-        unsigned long long win = 0;
-        uint32_t navail = 0;
-        while (open && !err) {
-            if (bp >= bit_end || nn >= 2u * kNumSym - 1) {
-                err = 1;
-                break;
+    uint32_t my_err = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        if (isnode[q]) {
+            const uint32_t pp = 3u * tid + q;
+            const uint32_t id = run & 0xFFFFu, leaves_before = run >> 16;
+            const uint32_t open_after = 1u + (id + 1u - (leaves_before + isleaf[q])) - (leaves_before + isleaf[q]);
+            if (id < 2u * kNumSym - 1) {
+                const uint32_t sym = (peek32(d.stage, bit0 + pp) >> 1) & 511u;
+                d.node[id] = isleaf[q] ? (kNodeLeaf | sym) : 0u;
+                // (t_open and friends live in cend, the marks in lut + the head of cend: write them after the barrier below)
+                if (isleaf[q] && open_after == 0) atomicMin(&d.endpos, pp);
             }
-            if (navail < 10) {
-                // (readfirstlane: one lane runs this loop, so everything it computes is wave-uniform and the compiler
-                // keeps the parse state in SGPRs, on the scalar unit)
-                const uint32_t wi = bp >> 5, sh = bp & 31u;
-                const uint32_t w_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.stage[wi]);
-                const uint32_t w_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.stage[wi + 1]);
-                win = ((unsigned long long)w_lo | ((unsigned long long)w_hi << 32)) >> sh;
-                navail = 64 - sh;
-            }
-            const uint32_t leaf = (uint32_t)win & 1u;
-            const uint32_t sym = ((uint32_t)win >> 1) & 511u;
-            const uint32_t used = leaf ? 10u : 1u;
-            if (leaf && (sym > 260 || nleaf >= (uint32_t)kNumSym)) {
-                err = 1;
-                break;
-            }
-            open = leaf ? open - 1 : open + 1;
-            d.node[nn] = leaf ? (kNodeLeaf | sym) : 0u;
-            t_open[nn] = (uint16_t)open;
-            t_ord[nn] = (uint16_t)nleaf;
-            nleaf += leaf;
-            ++nn;
-            win >>= used;
-            navail -= used;
-            bp += used;
+            run += 1u | (isleaf[q] << 16);
         }
-        if (bp > bit_end) err = 1;
-        d.nleaf = nleaf;
-        d.nnode = nn;
-        d.err = err;
-        d.code0 = bp;  // where the codes start
-        t_par[0] = 0;
     }
-    __syncthreads();
-    if (d.err) {
+    __syncthreads();  // endpos is final; all marks have been consumed
+    const uint32_t endpos = d.endpos;
+    run = tpre + tincl - packed;
+#pragma unroll
+    for (uint32_t q = 0; q < 3; ++q) {
+        if (isnode[q]) {
+            const uint32_t pp = 3u * tid + q;
+            const uint32_t id = run & 0xFFFFu, leaves_before = run >> 16;
+            if (pp <= endpos && id < kNodeSlots) {
+                const uint32_t lv = leaves_before + isleaf[q];
+                t_open[id] = (uint16_t)(1u + (id + 1u - lv) - lv);
+                t_ord[id] = (uint16_t)leaves_before;
+                if (isleaf[q] && (d.node[id] & 511u) > 260u) my_err = 1;
+                if (pp == endpos) {
+                    d.nnode = id + 1;
+                    d.nleaf = lv;
+                    d.code0 = bit0 + pp + 10;  // where the codes start
+                }
+            }
+            run += 1u | (isleaf[q] << 16);
+        }
+    }
+    if (tid == 0) t_par[0] = 0;
+    // no complete tree inside the payload, too many nodes, or a symbol out of range
+    if (__syncthreads_or((int)(my_err || endpos == 0xFFFFFFFFu || endpos >= P))) {
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
+    if (d.nnode > 2u * kNumSym - 1 || d.nleaf > (uint32_t)kNumSym || d.code0 > bit_end) {  // (block-uniform)
+        if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+        return;
+    }
+    for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;  // (steps B / C below fill it)
     const uint32_t nn = d.nnode, nleaf = d.nleaf;
     for (uint32_t i = tid; i < nn; i += kDecThreads) {  // B
         if (!(d.node[i] & kNodeLeaf)) {
