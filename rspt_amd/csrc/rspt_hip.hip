@@ -160,6 +160,7 @@ struct rspt_hip_packer {
 
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
+    uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
     uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
 
@@ -195,7 +196,7 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     const uint32_t ntiles = (uint32_t)((g.ns + T - 1) / T * nblocks);
     const uint32_t per_cu = lds <= 40 * 1024 ? 4u : lds <= 80 * 1024 ? 2u : 1u;
     uint32_t want = per_cu * (uint32_t)p->num_cu;
-    if (const char* e = getenv("RSPT_K1_GRID")) want = (uint32_t)atoi(e);
+    if (p->k1_grid) want = p->k1_grid;
     dim3 grid(want < ntiles ? want : ntiles);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(p->k1_threads), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate, (uint32_t)nblocks,
@@ -385,6 +386,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     }
     if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
+    if (const char* e = getenv("RSPT_K1_GRID")) p->k1_grid = (uint32_t)atoi(e);
     if (p->k1_threads < 64 || p->k1_threads > 1024) p->k1_threads = 256;
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
     {
