@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
-for cfg in "256 384 512" "256 256 768" "256 256 512" "256 192 768" "256 176 1024" "256 128 1024" "128 384 512" "128 384 1024"; do
+for cfg in "256 384 512" "256 768 256" "512 768 256" "1024 768 256" "512 640 256"; do
   set -- $cfg
   RSPT_K1_THREADS=$1 RSPT_TILE=$2 RSPT_K1_GRID=$3 timeout -k 10 100 python bench.py --steps 10 --warmup 2 --no-cpu 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('threads=$1 tile=$2 grid=$3', d['value'], d['roofline']['kernel_ms']['preprocess'])" || exit 1
 done
