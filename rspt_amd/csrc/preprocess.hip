@@ -90,7 +90,7 @@ struct ItemRegs {
 // item q (channel q % nch, samples [s0 + 16 (q / nch), +16)) of the tile [s0, s0 + Tn) of block `blk`
 template <int BPS, bool XDELTA>
 __device__ __forceinline__ void load_item(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t Tn, bool aligned4,
-                                          uint32_t ablate, uint32_t q, ItemRegs& R) {
+                                          uint32_t q, ItemRegs& R) {
     const size_t rstride = (size_t)g.nch * BPS;
     const uint32_t grp = fast_div(q, g.nch, m_nch);
     const uint32_t c = q - grp * g.nch;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void load_item(const uint8_t* blk, const Geom& g, uin
     const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
     if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (ablate & 32768u) ? 0u : (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
     } else {
 #pragma unroll
         for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
@@ -113,6 +113,123 @@ __device__ __forceinline__ void load_item(const uint8_t* blk, const Geom& g, uin
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
             R.p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
             R.p2 = (uint32_t)sample_global<BPS>(blk, g, flat - 2);
+        }
+    }
+}
+
+// what an item's transform needs to know about its tile
+struct TileCtx {
+    Geom g;
+    uint32_t m_nch, s0, Tn, b, kfirst, kcount, RS, ablate;
+    bool fixup;
+    uint8_t* out;      // LDS rows [plane][channel][RS]
+    uint32_t* s_nz;    // LDS dedupe masks [rel][plane][channel]
+    uint32_t* nzflag;  // HBM non-zero map
+};
+
+// item q, its 18 samples in R: transform, plane split into the LDS rows, non-zero map, escalation magnitude
+template <int BPS, bool XDELTA>
+__device__ __forceinline__ void transform_item(const ItemRegs& R, uint32_t q, const TileCtx& tc, uint32_t& mag, uint32_t& nz_seg,
+                                               uint32_t& nz_done) {
+    const Geom& g = tc.g;
+    const uint32_t m_nch = tc.m_nch, s0 = tc.s0, Tn = tc.Tn, b = tc.b, kfirst = tc.kfirst, kcount = tc.kcount, RS = tc.RS, ablate = tc.ablate;
+    const bool fixup = tc.fixup;
+    uint8_t* out = tc.out;
+    uint32_t* s_nz = tc.s_nz;
+    uint32_t* nzflag = tc.nzflag;
+    const uint32_t grp = fast_div(q, g.nch, m_nch);
+    const uint32_t c = q - grp * g.nch;
+    const uint32_t t0 = grp << 4;
+    const uint32_t cnt = min(16u, Tn - t0);
+    uint32_t p1 = R.p1, oprev = 0;  // p[i-1], o[i-1]
+    if (XDELTA) {
+        const bool flat0 = (c | s0 | t0) == 0;  // first element of the flat array: delta_encode and xor_encode_32 start from 0
+        p1 = flat0 ? 0u : R.p1;
+        oprev = flat0 ? 0u : (R.p1 - R.p2 - 128u);
+    }
+    const uint32_t* pv = R.pv;
+    uint32_t vv[16];
+    if (cnt == 16) {  // (all but the last group of a ragged tile)
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            const uint32_t p = pv[e];
+            if (XDELTA) {
+                const uint32_t o = p - p1 - 128u;
+                vv[e] = o ^ oprev;
+                oprev = o;
+                p1 = p;
+                // sign-extend from the sample width, fold to a magnitude (escalation test)
+                const int32_t x = BPS < 4 ? ((int32_t)(vv[e] << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)vv[e];
+                mag |= (uint32_t)(x ^ (x >> 31));
+            } else {
+                vv[e] = p;
+            }
+        }
+    } else {
+        // elements past cnt are computed on zeros and never stored or flagged: their plane bytes are masked off
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            const uint32_t p = pv[e];
+            uint32_t v;
+            if (XDELTA) {
+                const uint32_t o = p - p1 - 128u;
+                v = o ^ oprev;
+                oprev = o;
+                p1 = p;
+                const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
+                mag |= e < cnt ? (uint32_t)(x ^ (x >> 31)) : 0u;
+            } else {
+                v = p;
+            }
+            vv[e] = e < cnt ? v : 0u;
+        }
+    }
+    // byte-plane split of four samples at a time: a 4 x 4 byte transpose in 8 v_perm_b32
+    // (selector bytes 0-3 pick from the second operand, 4-7 from the first)
+    uint32_t pw[4][4];
+#pragma unroll
+    for (uint32_t g4 = 0; g4 < 4; ++g4) {
+        const uint32_t a0 = vv[4 * g4], a1 = vv[4 * g4 + 1], a2 = vv[4 * g4 + 2], a3 = vv[4 * g4 + 3];
+        const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
+        const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
+        pw[0][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+        pw[1][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+        pw[2][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+        pw[3][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+    }
+    uint32_t nzm = 0;  // bit k: plane k of this item holds a non-zero byte
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k >= kfirst && k < kfirst + kcount)
+            *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+        nzm |= ((pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0 ? 1u : 0u) << k;
+    }
+    // Non-zero map.  A thread mostly walks along one channel, and a tile row spans at most two 4 KiB segments: the
+    // bits this thread has already forwarded for the segment it is in live in a register, so the common item costs
+    // a compare and no LDS round trip.
+    if (!fixup && !(ablate & 65536u)) {
+        const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
+        const uint32_t seg = f0 >> 12;
+        if (seg != nz_seg) {
+            nz_seg = seg;
+            nz_done = 0;
+        }
+        const bool two = (f1 >> 12) != seg;  // (an item straddling a segment edge marks both sides: conservative)
+        const uint32_t need = two ? nzm : (nzm & ~nz_done);
+        nz_done |= nzm;
+        if (need) {
+            const uint32_t jb = (c * g.ns + s0) >> 16;
+            const uint32_t ja = f0 >> 16, jz = f1 >> 16;
+            const uint32_t ba = 1u << (seg & 15u), bz = 1u << ((f1 >> 12) & 15u);
+            uint32_t* za = &s_nz[((ja - jb) * 4) * g.nch + c];
+            uint32_t* zz = &s_nz[((jz - jb) * 4) * g.nch + c];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                if (!((need >> k) & 1u)) continue;
+                // the first setter in the workgroup forwards the bit to HBM (fire-and-forget)
+                if (!(atomicOr(&za[k * g.nch], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
+                if (two && !(atomicOr(&zz[k * g.nch], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
+            }
         }
     }
 }
@@ -157,7 +274,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         const uint32_t s0f = tile_s0(work), Tnf = min(T, g.ns - s0f);
         const uint8_t* blkf = src + (size_t)(work / tiles_per_block) * g.block_bytes;
         if (tid < g.nch * ((Tnf + 15) >> 4))
-            load_item<BPS, XDELTA>(blkf, g, m_nch, s0f, Tnf, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkf) & 3u) == 0), ablate, tid, cur);
+            load_item<BPS, XDELTA>(blkf, g, m_nch, s0f, Tnf, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkf) & 3u) == 0), tid, cur);
     }
     while (work < total) {
     const uint32_t b = work / tiles_per_block;
@@ -176,6 +293,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     for (uint32_t i = tid; i < 8 * g.nch; i += nthr) s_nz[i] = 0;
     __syncthreads();
 
+    const TileCtx tc{g, m_nch, s0, Tn, b, kfirst, kcount, RS, ablate, fixup, out, s_nz, nzflag};
     // ---- per (channel, 16-sample group): load, transform, plane split ---------
     const uint32_t ngrp = (Tn + 15) >> 4;
     const uint32_t nitems = g.nch * ngrp;
@@ -185,106 +303,13 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     uint32_t nz_seg = 0xFFFFFFFFu, nz_done = 0;  // segment (flat index >> 12) this thread is in, planes already flagged for it
     uint32_t q = tid;
     bool have = q < nitems;  // (item `tid` is in `cur` already)
-    if (q + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, q + nthr, nxt);
+    if (q + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, q + nthr, nxt);
     while (have) {
         const uint32_t qn = q + nthr;
         const bool have_next = qn < nitems;
         // two items ahead: ~36 row-segment loads (9 KiB) in flight per wave while this item is transformed
-        if (qn + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, ablate, qn + nthr, nx2);
-        const uint32_t grp = fast_div(q, g.nch, m_nch);
-        const uint32_t c = q - grp * g.nch;
-        const uint32_t t0 = grp << 4;
-        const uint32_t cnt = min(16u, Tn - t0);
-        uint32_t p1 = cur.p1, oprev = 0;  // p[i-1], o[i-1]
-        if (XDELTA) {
-            const int64_t flat = (int64_t)c * g.ns + s0 + t0;
-            oprev = (flat == 0) ? 0u : (cur.p1 - cur.p2 - 128u);  // xor_encode_32 starts from last = 0
-        }
-        const uint32_t* pv = cur.pv;
-        uint32_t vv[16];
-        if (cnt == 16) {  // (all but the last group of a ragged tile)
-#pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) {
-                const uint32_t p = pv[e];
-                if (XDELTA) {
-                    const uint32_t o = p - p1 - 128u;
-                    vv[e] = o ^ oprev;
-                    oprev = o;
-                    p1 = p;
-                    // sign-extend from the sample width, fold to a magnitude (escalation test)
-                    const int32_t x = BPS < 4 ? ((int32_t)(vv[e] << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)vv[e];
-                    mag |= (uint32_t)(x ^ (x >> 31));
-                } else {
-                    vv[e] = p;
-                }
-            }
-        } else {
-            // elements past cnt are computed on zeros and never stored or flagged: their plane bytes are masked off
-#pragma unroll
-            for (uint32_t e = 0; e < 16; ++e) {
-                const uint32_t p = pv[e];
-                uint32_t v;
-                if (XDELTA) {
-                    const uint32_t o = p - p1 - 128u;
-                    v = o ^ oprev;
-                    oprev = o;
-                    p1 = p;
-                    const int32_t x = BPS < 4 ? ((int32_t)(v << (32 - 8 * BPS)) >> (32 - 8 * BPS)) : (int32_t)v;
-                    mag |= e < cnt ? (uint32_t)(x ^ (x >> 31)) : 0u;
-                } else {
-                    v = p;
-                }
-                vv[e] = e < cnt ? v : 0u;
-            }
-        }
-        // byte-plane split of four samples at a time: a 4 x 4 byte transpose in 8 v_perm_b32
-        // (selector bytes 0-3 pick from the second operand, 4-7 from the first)
-        uint32_t pw[4][4];
-#pragma unroll
-        for (uint32_t g4 = 0; g4 < 4; ++g4) {
-            const uint32_t a0 = vv[4 * g4], a1 = vv[4 * g4 + 1], a2 = vv[4 * g4 + 2], a3 = vv[4 * g4 + 3];
-            const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
-            const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
-            pw[0][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
-            pw[1][g4] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
-            pw[2][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
-            pw[3][g4] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
-        }
-        uint32_t nzm = 0;  // bit k: plane k of this item holds a non-zero byte
-#pragma unroll
-        for (uint32_t k = 0; k < 4; ++k) {
-            if (k >= kfirst && k < kfirst + kcount)
-                *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
-            nzm |= ((pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0 ? 1u : 0u) << k;
-        }
-        // Non-zero map.  A thread mostly walks along one channel, and a tile row spans at most two 4 KiB segments: the
-        // bits this thread has already forwarded for the segment it is in live in a register, so the common item costs
-        // a compare and no LDS round trip.
-        if (!fixup && !(ablate & 65536u)) {
-            const uint32_t f0 = c * g.ns + s0 + t0, f1 = f0 + cnt - 1;  // flat range of this item
-            const uint32_t seg = f0 >> 12;
-            if (seg != nz_seg) {
-                nz_seg = seg;
-                nz_done = 0;
-            }
-            const bool two = (f1 >> 12) != seg;  // (an item straddling a segment edge marks both sides: conservative)
-            const uint32_t need = two ? nzm : (nzm & ~nz_done);
-            nz_done |= nzm;
-            if (need) {
-                const uint32_t jb = (c * g.ns + s0) >> 16;
-                const uint32_t ja = f0 >> 16, jz = f1 >> 16;
-                const uint32_t ba = 1u << (seg & 15u), bz = 1u << ((f1 >> 12) & 15u);
-                uint32_t* za = &s_nz[((ja - jb) * 4) * g.nch + c];
-                uint32_t* zz = &s_nz[((jz - jb) * 4) * g.nch + c];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    if (!((need >> k) & 1u)) continue;
-                    // the first setter in the workgroup forwards the bit to HBM (fire-and-forget)
-                    if (!(atomicOr(&za[k * g.nch], ba) & ba)) atomicOr(&nzflag[hb_index(g, b, k, ja)], ba);
-                    if (two && !(atomicOr(&zz[k * g.nch], bz) & bz)) atomicOr(&nzflag[hb_index(g, b, k, jz)], bz);
-                }
-            }
-        }
+        if (qn + nthr < nitems) load_item<BPS, XDELTA>(blk, g, m_nch, s0, Tn, aligned4, qn + nthr, nx2);
+        transform_item<BPS, XDELTA>(cur, q, tc, mag, nz_seg, nz_done);
         cur = nxt;
         nxt = nx2;
         q = qn;
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         const uint32_t s0n = tile_s0(work_next), Tnn = min(T, g.ns - s0n);
         const uint8_t* blkn = src + (size_t)(work_next / tiles_per_block) * g.block_bytes;
         if (tid < g.nch * ((Tnn + 15) >> 4))
-            load_item<BPS, XDELTA>(blkn, g, m_nch, s0n, Tnn, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkn) & 3u) == 0), ablate, tid, cur);
+            load_item<BPS, XDELTA>(blkn, g, m_nch, s0n, Tnn, (BPS == 4) && ((reinterpret_cast<uintptr_t>(blkn) & 3u) == 0), tid, cur);
     }
     if (XDELTA && !fixup) {
         // only the three thresholds matter (need_from_mask): fold to the top bit of each byte range, and
@@ -329,6 +354,196 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     }
     work = work_next;
     }  // tile loop
+    // main pass: the last workgroup to get here runs the escalation scan over the blocks (saves a launch and its gap)
+    if (ticket) {
+        __shared__ uint32_t s_last, s_wmax[16];
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();  // this workgroup's needmask atomics are out
+            s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            nb_scan_body(needmask, nblocks, nb_state, nbuse_out, XDELTA ? 1 : 0, s_wmax);
+        }
+    }
+}
+
+// ---- streaming form of k_tile_planes (aligned int32 samples, ns a multiple of 16, 256 threads) ---------------------------
+// Same tiles, same LDS rows, same stores; what differs is how the input gets here.  k_tile_planes' loads go through the
+// compiler's wait-count bookkeeping, which drains the whole queue (vmcnt(0)) before every item across that kernel's
+// control flow: one item's loads in flight per wave, 2.9 TB/s.  Here a thread's items form one stream across its
+// workgroup's tiles, held in a ring of three register sets.  A set is refilled (item three ahead, of this tile or the
+// next) straight after its item has been transformed, by loads issued from inline asm, and the consumer waits with an
+// explicit count: loads return in issue order, exactly two sets (2 x 18 loads) are issued behind any set, and whatever
+// the compiler adds in between (plane stores, flag atomics) is younger still -- "at most 36 outstanding" therefore
+// means the set has landed, with two items' worth of loads (9 KiB per wave) still in flight, also across the store
+// phase.  Every load and every wait is unconditional and sits in one place per set: the ring registers meet no
+// control-flow join, so the compiler has no reason to copy a register whose load is in flight
+// (tools/check_stream_regs.py checks the generated code for exactly that).  A stream that has run out of tiles keeps
+// loading item 0 of block 0; lanes past a tile's item count load its last item and skip the transform.
+__device__ __forceinline__ uint32_t stream_load_dword(const uint8_t* base, uint32_t off) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
+    return v;
+}
+template <bool XDELTA>
+__device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t q, ItemRegs& R) {
+    const uint32_t rstride = g.nch * 4u;
+    const uint32_t grp = fast_div(q, g.nch, m_nch);
+    const uint32_t c = q - grp * g.nch;
+    const uint32_t t = s0 + (grp << 4);
+    const uint32_t off = (t * g.nch + c) * 4u;  // (block_bytes < 4 GiB: the host checks)
+#pragma unroll
+    for (uint32_t e = 0; e < 16; ++e) R.pv[e] = stream_load_dword(blk, off + e * rstride);
+    if (XDELTA) {
+        // channel start: the flat array continues from the end of channel c-1 (flat index 0: patched by the consumer)
+        const uint32_t cm = c ? c - 1 : 0u;
+        const uint32_t o1 = t ? off - rstride : ((g.ns - 1) * g.nch + cm) * 4u;
+        const uint32_t o2 = t ? off - 2 * rstride : ((g.ns - 2) * g.nch + cm) * 4u;
+        R.p1 = stream_load_dword(blk, o1);
+        R.p2 = stream_load_dword(blk, o2);
+    } else {
+        R.p1 = R.p2 = 0;
+    }
+}
+// the set's registers pass through the wait, so nothing that reads them can be scheduled above it
+template <int N>
+__device__ __forceinline__ void item_wait(ItemRegs& R) {
+    asm volatile("s_waitcnt vmcnt(%18)"
+                 : "+v"(R.pv[0]), "+v"(R.pv[1]), "+v"(R.pv[2]), "+v"(R.pv[3]), "+v"(R.pv[4]), "+v"(R.pv[5]), "+v"(R.pv[6]), "+v"(R.pv[7]),
+                   "+v"(R.pv[8]), "+v"(R.pv[9]), "+v"(R.pv[10]), "+v"(R.pv[11]), "+v"(R.pv[12]), "+v"(R.pv[13]), "+v"(R.pv[14]),
+                   "+v"(R.pv[15]), "+v"(R.p1), "+v"(R.p2)
+                 : "n"(N));
+}
+
+template <bool XDELTA>
+__global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
+                                                    uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
+                                                    uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
+                                                    uint32_t nblocks, uint32_t* __restrict__ ticket, uint32_t* __restrict__ nb_state,
+                                                    uint32_t* __restrict__ nbuse_out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr uint32_t nthr = 256;
+    constexpr int kAhead = 2 * (XDELTA ? 18 : 16);  // hand-issued loads of the two younger sets
+    const uint32_t tid = threadIdx.x;
+    const bool fixup = nbuse != nullptr;
+    const uint32_t tiles_per_block = (g.ns + T - 1) / T;
+    const uint32_t total = tiles_per_block * nblocks;
+    const uint32_t m_nch = magic_of(g.nch);
+    auto skip_untouched = [&](uint32_t wk) {  // (the fix-up pass touches only the blocks whose nb grew past kfirst)
+        while (wk < total && fixup && nbuse[wk / tiles_per_block] <= kfirst) wk += gridDim.x;
+        return wk;
+    };
+    auto tile_s0 = [&](uint32_t wk) { return (wk - (wk / tiles_per_block) * tiles_per_block) * T; };
+    auto tile_items = [&](uint32_t s0_) { return g.nch * (min(T, g.ns - s0_) >> 4); };  // (ns % 16 == 0)
+
+    // ---- load side of the stream: tile lw, ordinal lj of its l_ipt ----
+    uint32_t lw = skip_untouched(blockIdx.x), lj = 0, l_s0 = 0, l_nitems = 1, l_ipt = 0xFFFFFFFFu;
+    const uint8_t* l_blk = src;
+    auto l_open = [&]() {
+        if (lw < total) {
+            l_s0 = tile_s0(lw);
+            l_nitems = tile_items(l_s0);
+            l_ipt = (l_nitems + nthr - 1) / nthr;
+            l_blk = src + (size_t)(lw / tiles_per_block) * g.block_bytes;
+        } else {  // out of tiles: keep the ring turning on item 0 of block 0
+            l_s0 = 0;
+            l_nitems = 1;
+            l_ipt = 0xFFFFFFFFu;
+            l_blk = src;
+        }
+    };
+    auto fetch = [&](ItemRegs& R) __attribute__((always_inline)) {
+        load_item_stream<XDELTA>(l_blk, g, m_nch, l_s0, min(tid + lj * nthr, l_nitems - 1), R);
+        if (++lj == l_ipt) {
+            lw = skip_untouched(lw + gridDim.x);
+            lj = 0;
+            l_open();
+        }
+    };
+
+    // ---- transform side: tile tw, ordinal tj of its t_ipt ----
+    uint32_t tw = lw, tj = 0, t_ipt = 0, t_nitems = 0;
+    uint32_t mag = 0, nz_seg = 0xFFFFFFFFu, nz_done = 0;
+    const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
+    uint8_t* out = lds;
+    uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)kcount * g.nch * RS);
+    TileCtx tc{g, m_nch, 0, 0, 0, kfirst, kcount, RS, ablate, fixup, out, s_nz, nzflag};
+    auto t_open = [&]() {
+        tc.b = tw / tiles_per_block;
+        tc.s0 = tile_s0(tw);
+        tc.Tn = min(T, g.ns - tc.s0);
+        t_nitems = tile_items(tc.s0);
+        t_ipt = (t_nitems + nthr - 1) / nthr;
+        tj = 0;
+        mag = 0;
+        nz_seg = 0xFFFFFFFFu;
+        nz_done = 0;
+        __syncthreads();  // the previous tile's rows have left LDS
+        for (uint32_t i = tid; i < 8 * g.nch + 1; i += nthr) s_nz[i] = 0;  // (+1: the tile's escalation bits)
+        __syncthreads();
+    };
+    auto t_close = [&]() {
+        // Escalation magnitude: only the three thresholds matter (need_from_mask).  The workgroup folds them in LDS and
+        // sends one fire-and-forget atomic per tile -- a read of needmask[b] to skip redundant ones would be a
+        // compiler-tracked load queued behind the ring's prefetch, i.e. a full drain of the stream once per tile.
+        if (XDELTA && !fixup) {
+            mag = wave_or_u32(mag);
+            const uint32_t f = (mag >= 0x80u ? 0x80u : 0u) | (mag >= 0x8000u ? 0x8000u : 0u) | (mag >= 0x800000u ? 0x800000u : 0u);
+            if (lane_id() == 0 && f) atomicOr(&s_nz[8 * g.nch], f);
+        }
+        __syncthreads();
+        if (XDELTA && !fixup && tid == 0) {
+            const uint32_t f = s_nz[8 * g.nch];
+            if (f && !(ablate & 131072u)) atomicOr(&needmask[tc.b], f);
+        }
+        // plane rows -> HBM: 16-byte units, T contiguous bytes per (plane, channel)
+        const uint32_t upr = tc.Tn >> 4;
+        const uint32_t nunits = kcount * g.nch * upr;
+        const uint32_t m_upr = magic_of(upr);
+        for (uint32_t u = tid; u < nunits; u += nthr) {
+            const uint32_t row = fast_div(u, upr, m_upr);  // (k-kfirst)*nch + c
+            const uint32_t colu = u - row * upr;
+            const uint32_t kr = fast_div(row, g.nch, m_nch);
+            const uint32_t c = row - kr * g.nch;
+            const uint8_t* sp = out + (size_t)row * RS + colu * 16;
+            uint8_t* dp = planes + ((size_t)tc.b * kMaxPlanes + kfirst + kr) * g.plane_stride + (size_t)c * g.ns + tc.s0 + colu * 16;
+            if (ablate & 16384u) continue;  // timing probe: no stores
+            *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+        }
+    };
+    // one turn of the ring for set R; true when the stream's last tile has been stored
+    auto turn = [&](ItemRegs& R) __attribute__((always_inline)) -> bool {
+        item_wait<kAhead>(R);
+        const uint32_t q = tid + tj * nthr;
+        if (q < t_nitems) transform_item<4, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
+        fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
+        if (++tj == t_ipt) {
+            t_close();
+            tw = skip_untouched(tw + gridDim.x);
+            if (tw >= total) return true;
+            t_open();
+        }
+        return false;
+    };
+
+    if (tw < total) {
+        l_open();
+        ItemRegs ra, rb, rc;
+        fetch(ra);
+        fetch(rb);
+        fetch(rc);
+        t_open();
+        for (;;) {
+            if (turn(ra)) break;
+            if (turn(rb)) break;
+            if (turn(rc)) break;
+        }
+        // the ring's last refills are still in flight and their registers are free for reuse from here on: let them land
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // main pass: the last workgroup to get here runs the escalation scan over the blocks (saves a launch and its gap)
     if (ticket) {
         __shared__ uint32_t s_last, s_wmax[16];
@@ -531,6 +746,8 @@ INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
+template __global__ void k_tile_stream<true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_tile_stream<false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 

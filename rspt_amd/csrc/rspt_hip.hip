@@ -192,12 +192,21 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
                           hipStream_t st) {
     const Geom& g = p->g;
     const uint32_t T = p->Tp[kcount];
-    const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch;
+    const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch + 16u;
     const uint32_t ntiles = (uint32_t)((g.ns + T - 1) / T * nblocks);
     const uint32_t per_cu = lds <= 40 * 1024 ? 4u : lds <= 80 * 1024 ? 2u : 1u;
     uint32_t want = per_cu * (uint32_t)p->num_cu;
     if (p->k1_grid) want = p->k1_grid;
     dim3 grid(want < ntiles ? want : ntiles);
+    // aligned int32 input in whole 16-sample groups streams (k_tile_stream); anything else takes the general kernel
+    const bool stream = BPS == 4 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && (g.ns & 15u) == 0 && g.block_bytes < (1ull << 32) &&
+                        !(p->ablate & (1u << 22));
+    if (stream) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_stream<XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_tile_stream<XD>), grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate,
+                           (uint32_t)nblocks, nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse);
+        return;
+    }
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_tile_planes<BPS, XD>), grid, dim3(p->k1_threads), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate, (uint32_t)nblocks,
                        nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse);
@@ -367,7 +376,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         // lines beat ragged ones of about the same length (384 vs 352: -4 %).
         for (uint32_t kc = 1; kc <= 4; ++kc) {
             auto fit = [&](uint64_t budget) -> uint32_t {
-                const uint64_t fixed = (16ull * kc + 32ull) * g.nch;
+                const uint64_t fixed = (16ull * kc + 32ull) * g.nch + 16;  // row padding, non-zero dedupe masks, escalation word
                 if (budget <= fixed) return 0;
                 uint64_t tt = (budget - fixed) / ((uint64_t)kc * g.nch);
                 tt &= tt >= 256 ? ~127ull : ~15ull;
@@ -387,7 +396,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
     if (const char* e = getenv("RSPT_K1_GRID")) p->k1_grid = (uint32_t)atoi(e);
-    if (p->k1_threads < 64 || p->k1_threads > 1024) p->k1_threads = 256;
+    if (p->k1_threads < 64 || p->k1_threads > 256) p->k1_threads = 256;  // (k_tile_planes is compiled for <= 256)
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
     {
         // k_planar_native tile: nch rows of (T+1) int32 within 64 KiB
