@@ -184,6 +184,11 @@ __device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, u
 // "Small" hzr blocks -- few non-zero 4 KiB segments -- are walked by ONE wave, row by row, instead of
 // by a 1024-thread workgroup: their histogram is taken inside k_tree (k_hist skips them) and, if they
 // also have few tokens and a small payload, they are encoded by k_encode_small.
+// Clean-block invariant (rspt_hip_packer::plane_dirty): a Huffman block with at most this many tokens has its non-zero
+// granules wiped by the encoder that read it; k_layout flags every other block that holds a non-zero byte as dirty.
+// (Every small block qualifies: kSmallTokens <= kWipeTokens.)
+constexpr uint32_t kWipeTokens = 2048;
+__device__ __forceinline__ bool block_is_wiped(const BlockMeta& m) { return m.mode == kModeHuff && m.fill <= kWipeTokens; }
 constexpr uint32_t kSmallSegments = 2;    // non-zero 4 KiB segments (each costs one dependent HBM round trip)
 constexpr uint32_t kSmallTokens = 512;    // tokens
 constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
@@ -701,9 +706,12 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
                                                const uint8_t* __restrict__ means_hdr, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes, const CrcConsts* __restrict__ cc,
                                                const uint32_t* __restrict__ nzflag, WorkQueues* __restrict__ wq,
-                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list) {
+                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list,
+                                               uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
     __shared__ uint64_t s_part[256];
     __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
+    __shared__ uint32_t s_dirty[kMaxPlanes * 4];  // 128 bits per plane: hzr blocks (j >> dirty_shift) that keep their data
+    if (threadIdx.x < kMaxPlanes * 4) s_dirty[threadIdx.x] = 0;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t nb = nbuse[b];
     const uint32_t n = nb * g.nblk;  // hzr blocks of this block, (k,j) order
@@ -714,7 +722,15 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
         return 7ull + meta[hb0 + q].payload_len;
     };
     uint64_t sum = 0;
-    for (uint32_t q = lo; q < hi; ++q) sum += enc_size(q);
+    __syncthreads();  // (s_dirty is zeroed)
+    for (uint32_t q = lo; q < hi; ++q) {
+        sum += enc_size(q);
+        // non-zero data that no encoder wipes (dense Huffman blocks, PlainCopy, constant non-zero blocks) stays behind
+        if (nzflag[hb0 + q] && !block_is_wiped(meta[hb0 + q])) {
+            const uint32_t k = q / g.nblk, bucket = (q - k * g.nblk) >> dirty_shift;
+            atomicOr(&s_dirty[k * 4 + (bucket >> 5)], 1u << (bucket & 31u));
+        }
+    }
     s_part[tid] = sum;
     __syncthreads();
     if (tid == 0) {
@@ -740,6 +756,8 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
     const uint64_t total = head + 8ull * nb + s_plane_end[nb];
     const bool fits = total <= dst_stride;
     if (tid == 0) sizes[b] = fits ? total : (total | (1ull << 63));
+    // the planes written in this call: dirty when a dense block stays behind, or when nothing will be encoded (and wiped) at all
+    if (tid < nb * 4) plane_dirty[(size_t)b * kMaxPlanes * 4 + tid] = fits ? s_dirty[tid] : 0xFFFFFFFFu;
     if (!fits) {  // tell k_encode to leave this block alone
         for (uint32_t q = lo; q < hi; ++q) out_off[hb0 + q] = ~0ull;
         return;
@@ -1028,7 +1046,7 @@ __device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q
 __shared__ EncLds g_enc;
 
 template <bool DIAG>
-__device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j, const uint8_t* __restrict__ planes, const Geom& g,
+__device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j, uint8_t* __restrict__ planes, const Geom& g,
                                              const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
                                              const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                              const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
@@ -1082,7 +1100,7 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
     }
 
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     const uint32_t L = m.payload_len;
     RSPT_STAMP(0);
 
@@ -1099,6 +1117,14 @@ __device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j,
         } else {
             load_with_chain(in, in_size, segmask, zbza + (size_t)hb * kHzrBlock / 16, B);  // k_hist went through this block
             __syncthreads();  // cw and the zeroed image are in place
+        }
+        if (block_is_wiped(m)) {
+            // clean-block invariant: a light block leaves zeros behind.  Each lane was the only reader of its granules.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const Granule& gr = B.g[r];
+                if (gr.nv && (gr.w[0] | gr.w[1] | gr.w[2] | gr.w[3])) *reinterpret_cast<uint4*>(in + w * 4096 + r * 1024 + l * 16) = make_uint4(0, 0, 0, 0);
+            }
         }
         if (ablate & 32u) return;
         RSPT_STAMP(1);
@@ -1303,7 +1329,7 @@ __device__ __forceinline__ uint32_t crc_chunk64_lin(const uint32_t* img, const u
 }
 
 __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img, const uint32_t (*crc_tab)[256], uint32_t hb,
-                                                   const uint8_t* __restrict__ planes, const Geom& g,
+                                                   uint8_t* __restrict__ planes, const Geom& g,
                                                    const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
                                                    const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                                    const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
@@ -1316,7 +1342,7 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
     const uint32_t segmask = nzflag[hb];
     if (off == ~0ull) return;
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
     const uint32_t L = m.payload_len;
     for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) cwt[i] = cw[(size_t)hb * kSymStride + i];
     for (uint32_t i = l; i < kSlotImage; i += 64) img[i] = 0;
@@ -1362,6 +1388,8 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
                     gr.w[3] = cur[r].w;
                     granule_finish(gr);
                     const uint32_t lits = ~gr.zm & ((1u << gr.nv) - 1u);
+                    // clean-block invariant: every small block is wiped (block_is_wiped); this lane alone read the granule
+                    if (lits) *reinterpret_cast<uint4*>(in + pos) = make_uint4(0, 0, 0, 0);
                     const unsigned long long nzb = __ballot(lits != 0);
                     if (!nzb) {
                         pend += row_valid;
@@ -1452,7 +1480,7 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+__global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
                                                           const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                           const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
@@ -1479,7 +1507,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(const uint8_t* __rest
 
 // small blocks: 4 waves per workgroup, each wave pulls blocks on its own (no workgroup barrier after the table load)
 constexpr int kSmallWaves = 4;
-__global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+__global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
                                                                   const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                                   const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                                   const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
@@ -1498,8 +1526,8 @@ __global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(const uint8_t
             i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
         }
         if (i >= n_small) break;
-        encode_small_block(s_slot[wv], s_slot[wv] + kSymStride, s_crc, small_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst,
-                           dst_stride, ablate);
+        const uint32_t hb = small_list[i];
+        encode_small_block(s_slot[wv], s_slot[wv] + kSymStride, s_crc, hb, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate);
     }
 }
 

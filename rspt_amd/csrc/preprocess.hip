@@ -418,12 +418,14 @@ __device__ __forceinline__ void item_wait(ItemRegs& R) {
                  : "n"(N));
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool XDELTA>
 __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
                                                     uint32_t nblocks, uint32_t* __restrict__ ticket, uint32_t* __restrict__ nb_state,
-                                                    uint32_t* __restrict__ nbuse_out) {
+                                                    uint32_t* __restrict__ nbuse_out, const uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr uint32_t nthr = 256;
     constexpr int kAhead = 2 * (XDELTA ? 18 : 16);  // hand-issued loads of the two younger sets
@@ -466,6 +468,21 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
 
     // ---- transform side: tile tw, ordinal tj of its t_ipt ----
     uint32_t tw = lw, tj = 0, t_ipt = 0, t_nitems = 0;
+    // dirty bits of the NEXT tile to open, [plane - kfirst]: scalar loads issued by hand one tile ahead (they do not queue
+    // behind the ring's vector loads, and their latency hides behind the store phase)
+    u32x4 dq0 = {0, 0, 0, 0}, dq1 = dq0, dq2 = dq0, dq3 = dq0;
+    auto dirty_fetch = [&](uint32_t wk) {
+        const uint32_t bb = wk < total ? wk / tiles_per_block : 0u;
+        auto at = [&](uint32_t kr) {
+            const uint64_t a = reinterpret_cast<uint64_t>(plane_dirty + ((size_t)bb * kMaxPlanes + min(kfirst + kr, kMaxPlanes - 1u)) * 4);
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+            return reinterpret_cast<const uint32_t*>(((uint64_t)hi << 32) | lo);
+        };
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dq0) : "s"(at(0)));
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dq1) : "s"(at(1)));
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dq2) : "s"(at(2)));
+        asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(dq3) : "s"(at(3)));
+    };
     uint32_t mag = 0, nz_seg = 0xFFFFFFFFu, nz_done = 0;
     const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
     uint8_t* out = lds;
@@ -483,6 +500,14 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         nz_done = 0;
         __syncthreads();  // the previous tile's rows have left LDS
         for (uint32_t i = tid; i < 8 * g.nch + 1; i += nthr) s_nz[i] = 0;  // (+1: the tile's escalation bits)
+        // which hzr blocks of this block's planes hold stale data: 128 bits per plane, fetched by dirty_fetch() a tile ago
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dq0), "+s"(dq1), "+s"(dq2), "+s"(dq3));
+        if (tid == 0) {
+            uint32_t* sd = s_nz + 8 * g.nch + 1;
+            const u32x4 dq[4] = {dq0, dq1, dq2, dq3};
+#pragma unroll
+            for (uint32_t i = 0; i < 16; ++i) sd[i] = dq[i >> 2][i & 3];
+        }
         __syncthreads();
     };
     auto t_close = [&]() {
@@ -502,6 +527,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         // plane rows -> HBM: 16-byte units, T contiguous bytes per (plane, channel)
         const uint32_t upr = tc.Tn >> 4;
         const uint32_t nunits = kcount * g.nch * upr;
+        const bool whole_lines = (upr & 7u) == 0 && !(ablate & (1u << 21));  // rows are whole 128-byte lines (else: store everything)
         const uint32_t m_upr = magic_of(upr);
         for (uint32_t u = tid; u < nunits; u += nthr) {
             const uint32_t row = fast_div(u, upr, m_upr);  // (k-kfirst)*nch + c
@@ -511,7 +537,16 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             const uint8_t* sp = out + (size_t)row * RS + colu * 16;
             uint8_t* dp = planes + ((size_t)tc.b * kMaxPlanes + kfirst + kr) * g.plane_stride + (size_t)c * g.ns + tc.s0 + colu * 16;
             if (ablate & 16384u) continue;  // timing probe: no stores
-            *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+            const uint4 v = *reinterpret_cast<const uint4*>(sp);
+            // a clean hzr block (zeros everywhere, see rspt_hip_packer::plane_dirty) only takes the 128-byte lines that hold
+            // a non-zero byte: a line is eight consecutive units = eight aligned lanes (T is a multiple of 128)
+            const unsigned long long bal = __ballot((v.x | v.y | v.z | v.w) != 0);
+            const bool line_nz = ((bal >> (lane_id() & ~7u)) & 0xFFull) != 0;
+            if (!line_nz && whole_lines) {
+                const uint32_t bucket = ((c * g.ns + tc.s0 + colu * 16) >> 16) >> dirty_shift;
+                if (!((s_nz[8 * g.nch + 1 + kr * 4 + (bucket >> 5)] >> (bucket & 31u)) & 1u)) continue;
+            }
+            *reinterpret_cast<uint4*>(dp) = v;
         }
     };
     // one turn of the ring for set R; true when the stream's last tile has been stored
@@ -521,8 +556,10 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         if (q < t_nitems) transform_item<4, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
         if (++tj == t_ipt) {
+            const uint32_t tw_next = skip_untouched(tw + gridDim.x);
+            dirty_fetch(tw_next);  // (consumed by t_open, after this tile's store phase)
             t_close();
-            tw = skip_untouched(tw + gridDim.x);
+            tw = tw_next;
             if (tw >= total) return true;
             t_open();
         }
@@ -535,6 +572,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         fetch(ra);
         fetch(rb);
         fetch(rc);
+        dirty_fetch(tw);
         t_open();
         for (;;) {
             if (turn(ra)) break;
@@ -746,8 +784,8 @@ INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
-template __global__ void k_tile_stream<true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_tile_stream<false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_tile_stream<true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 

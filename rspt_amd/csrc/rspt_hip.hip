@@ -117,6 +117,14 @@ struct rspt_hip_packer {
     uint32_t* small_list = nullptr;  // [cap*4*nblk] hzr blocks for the wave-per-block encoder
     int num_cu = 256;
     uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte
+    // Clean-block invariant (k_tile_stream's skipped stores): between calls, hzr block j of plane k of block slot b holds
+    // zeros everywhere unless its bit in plane_dirty is set (128 bits per plane, bit = j >> dirty_shift).  The streaming
+    // front end writes only the 128-byte lines that hold a non-zero byte into a clean block; k_layout sets the bits of
+    // the blocks in which data stays behind, and the encoders wipe the non-zero granules of all others right after
+    // reading them (light blocks only: block_is_wiped).
+    uint32_t* plane_dirty = nullptr;  // [cap*4][4]
+    uint32_t dirty_shift = 0;
+    bool planes_unknown = false;      // something else (decompress, a diagnostic run) wrote the planes: flag them all
     uint32_t* nb_state = nullptr;  // [1] persistent
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
     uint32_t* seghist = nullptr;   // [cap*4*nblk][16][264] u16: tokens starting in each 4 KiB segment (k_hist -> k_tree)
@@ -192,7 +200,7 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
                           hipStream_t st) {
     const Geom& g = p->g;
     const uint32_t T = p->Tp[kcount];
-    const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch + 16u;
+    const uint32_t lds = kcount * g.nch * (T + 16u) + 32u * g.nch + 96u;
     const uint32_t ntiles = (uint32_t)((g.ns + T - 1) / T * nblocks);
     const uint32_t per_cu = lds <= 40 * 1024 ? 4u : lds <= 80 * 1024 ? 2u : 1u;
     uint32_t want = per_cu * (uint32_t)p->num_cu;
@@ -204,7 +212,7 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     if (stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_stream<XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_tile_stream<XD>), grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate,
-                           (uint32_t)nblocks, nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse);
+                           (uint32_t)nblocks, nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse, p->plane_dirty, p->dirty_shift);
         return;
     }
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -293,6 +301,8 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planar);
     hipFree(p->nbuse);
     hipFree(p->nzflag);
+    hipFree(p->plane_dirty);
+    p->plane_dirty = nullptr;
     hipFree(p->big_list);
     hipFree(p->small_list);
     p->nzflag = p->big_list = p->small_list = nullptr;
@@ -376,7 +386,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
         // lines beat ragged ones of about the same length (384 vs 352: -4 %).
         for (uint32_t kc = 1; kc <= 4; ++kc) {
             auto fit = [&](uint64_t budget) -> uint32_t {
-                const uint64_t fixed = (16ull * kc + 32ull) * g.nch + 16;  // row padding, non-zero dedupe masks, escalation word
+                const uint64_t fixed = (16ull * kc + 32ull) * g.nch + 96;  // row padding, non-zero dedupe masks, escalation word + dirty bits
                 if (budget <= fixed) return 0;
                 uint64_t tt = (budget - fixed) / ((uint64_t)kc * g.nch);
                 tt &= tt >= 256 ? ~127ull : ~15ull;
@@ -565,6 +575,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     bool ok = true;
     ok &= hipMalloc(&p->planes, max_blocks * kMaxPlanes * g.plane_stride + 4096) == hipSuccess;
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->plane_dirty, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
     ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32) * sizeof(uint32_t)) == hipSuccess;
@@ -595,6 +606,13 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
         free_workspace(p);
         return RSPT_HIP_ERR_ALLOC;
     }
+    // the clean-plane invariant starts from zeroed planes
+    HIPCHK(p, hipMemset(p->planes, 0, max_blocks * kMaxPlanes * g.plane_stride + 4096));
+    HIPCHK(p, hipMemset(p->plane_dirty, 0, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)));
+    p->dirty_shift = 0;
+    while (((g.nblk - 1) >> p->dirty_shift) >= 128u) ++p->dirty_shift;
+    HIPCHK(p, hipDeviceSynchronize());  // (the calls that follow may come on any stream)
+    p->planes_unknown = false;
     p->cap_blocks = max_blocks;
     return RSPT_HIP_OK;
 }
@@ -618,6 +636,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         p->needmask = p->nzflag + nhb_call;
         p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
         HIPCHK(p, hipMemsetAsync(p->nzflag, 0, (size_t)((p->work_ctr + 16) - p->nzflag) * sizeof(uint32_t), st));
+    }
+    if (p->planes_unknown || p->ablate) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave)
+        HIPCHK(p, hipMemsetAsync(p->plane_dirty, 0xFF, p->cap_blocks * kMaxPlanes * 4 * sizeof(uint32_t), st));
+        p->planes_unknown = false;
     }
     uint32_t np = 4;
     switch (g.bps) {
@@ -667,7 +689,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_LAYOUT, st);
     WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
-                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list);
+                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift);
 
     stamp(p, ST_ENCODE, st);
     {
@@ -811,6 +833,7 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
     int rc = rspt_hip_reserve(p, nblocks);
     if (rc) return rc;
     HIPCHK(p, hipSetDevice(p->device));
+    p->planes_unknown = true;  // the decoded planes land in the compressor's plane workspace
     hipStream_t st = (hipStream_t)stream;
     {
         const Geom& g = p->g;

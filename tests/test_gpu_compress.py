@@ -162,3 +162,78 @@ def test_pack_batch_container(api, orc):
     # host-side packer produces the same bytes
     assert shard.pack_container(want, nb) == d_packed[:total].cpu().numpy().tobytes()
     pk.close()
+
+
+def _plane_mix(nch, ns, seed, kind):
+    """int32 blocks whose xdelta planes are dense / sparse / empty in chosen places."""
+    r = np.random.default_rng(seed)
+    if kind == "dense":  # all three low planes busy in every channel
+        x = r.integers(-(1 << 22), 1 << 22, (ns, nch))
+    elif kind == "quiet":  # plane 0 only, tiny steps
+        x = np.cumsum(r.integers(-3, 4, (ns, nch)), axis=0)
+    elif kind == "spikes":  # quiet + a handful of big spikes: planes 1 and 2 hold a few isolated bytes (sparse hzr blocks)
+        x = np.cumsum(r.integers(-3, 4, (ns, nch)), axis=0)
+        for _ in range(12):
+            x[r.integers(0, ns), r.integers(0, nch)] += int(r.integers(1 << 17, 1 << 21))
+    elif kind == "half":  # half of the channels dense, half silent: dense and all-zero hzr blocks in one plane
+        x = np.zeros((ns, nch), dtype=np.int64)
+        x[:, ::2] = r.integers(-(1 << 20), 1 << 20, (ns, (nch + 1) // 2))
+    elif kind == "const":  # constant non-zero samples: xdelta output is the constant -128 pattern after the first samples
+        x = np.full((ns, nch), 12345)
+    else:
+        x = np.zeros((ns, nch), dtype=np.int64)
+    return np.ascontiguousarray(x.astype("<i4")).view(np.uint8).reshape(-1)
+
+
+@pytest.mark.parametrize("ns", [4096, 65536 + 4096])
+def test_plane_workspace_carries_nothing_between_calls(api, orc, ns):
+    """The streaming front end leaves all-zero 128-byte lines of a clean plane unwritten and the encoders wipe the sparse
+    blocks they read (rspt_hip_packer::plane_dirty).  Whatever a call leaves in the plane workspace must never show in
+    a later stream: one packer, batches of changing size and content, every stream against the oracle -- including a
+    call whose output does not fit, a decompress in between (it decodes into the same workspace) and a single-block
+    compress()."""
+    import torch
+
+    nch = 8
+    po = orc.packer("xdelta_hzr", 4, nch, ns, 3)
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    script = [
+        ["dense", "quiet", "spikes", "half", "zero", "const"],
+        ["quiet", "quiet", "dense"],
+        ["spikes", "zero", "half", "dense", "quiet", "spikes", "const", "zero"],
+        ["zero"],
+        ["half", "spikes"],
+        ["quiet", "spikes", "quiet", "spikes", "zero", "dense"],
+    ]
+    seed = 0
+    last = None
+    for step, kinds in enumerate(script):
+        blocks = []
+        for kd in kinds:
+            seed += 1
+            blocks.append(_plane_mix(nch, ns, seed, kd))
+        d_src = torch.from_numpy(np.stack(blocks)).cuda()
+        if step == 2:  # first: the same batch into a destination that is too small for it (nothing is encoded, nothing wiped)
+            small = torch.empty((len(blocks), 64), dtype=torch.uint8, device="cuda")
+            nb_before = pk.nb
+            _, d_sz = pk.compress_batch(d_src, small, None, 64)
+            torch.cuda.synchronize()
+            assert (d_sz.cpu().numpy().view(np.uint64) >> np.uint64(63)).all()
+            pk.set_nb(nb_before)
+        if step == 4 and last is not None:  # a decode writes the workspace, too
+            dec, used = pk.decompress(last[1])
+            assert dec == last[0].tobytes() and used == len(last[1])
+            pk.set_nb(orc.packer_nb(po))
+        d_dst, d_sizes = pk.compress_batch(d_src)
+        torch.cuda.synchronize()
+        sizes = d_sizes.cpu().numpy()
+        out = d_dst.cpu().numpy()
+        for i, blk in enumerate(blocks):
+            want = po.compress(blk)
+            got = out[i, : sizes[i]].tobytes()
+            assert got == want, "call %d block %d (%s): %s" % (step, i, kinds[i], describe_mismatch(got, want))
+            last = (blk, got)
+        assert pk.nb == orc.packer_nb(po)
+    one = _plane_mix(nch, ns, 999, "spikes")
+    assert pk.compress(one) == po.compress(one)
+    pk.close()

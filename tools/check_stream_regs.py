@@ -23,8 +23,19 @@ def regs_of(tok):
     return out
 
 
+def sregs_of(tok):
+    out = []
+    for m in re.finditer(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]", tok):
+        if m.group(1) is not None:
+            out.append(int(m.group(1)))
+        else:
+            out.extend(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
 def check(lines, name):
     pending = []  # destination registers of hand-issued loads, oldest first
+    spending = set()  # destination SGPRs of hand-issued scalar loads (they return out of order: only lgkmcnt(0) clears them)
     in_asm = False
     bad = 0
     nload = nwait = 0
@@ -45,6 +56,15 @@ def check(lines, name):
                 pending.append(int(m.group(1)))
                 nload += 1
                 continue
+            m = re.match(r"s_load_dwordx4 s\[(\d+):(\d+)\],", code)
+            if m:
+                spending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                nload += 1
+                continue
+            if re.match(r"s_waitcnt lgkmcnt\(0\)", code):
+                spending = set()
+                nwait += 1
+                continue
             m = re.match(r"s_waitcnt vmcnt\((\d+)\)", code)
             if m:
                 n = int(m.group(1))
@@ -53,9 +73,17 @@ def check(lines, name):
                 continue
             continue
         m = re.match(r"s_waitcnt (.*)", code)
-        if m and "vmcnt(0)" in m.group(1):
-            pending = []
+        if m:
+            if "vmcnt(0)" in m.group(1):
+                pending = []
+            if "lgkmcnt(0)" in m.group(1):
+                spending = set()
             continue
+        if spending:
+            shit = set(sregs_of(code.split(None, 1)[1] if " " in code else "")) & spending
+            if shit:
+                bad += 1
+                print("%s: line %d touches in-flight SGPR %s: %s" % (name, ln, sorted(shit), code))
         if code.startswith("s_") and "v" not in code.split(None, 1)[-1]:
             continue
         touched = set(regs_of(code.split(None, 1)[1] if " " in code else ""))
