@@ -348,6 +348,9 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         if (ablate & 16384u) continue;  // timing probe: no stores
         if (fast && nbytes == 16) {
             *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+        } else if (nbytes == 16) {  // a row that starts at any byte alignment (ns not a multiple of 16): unaligned 16-byte store
+            const uint4 v = *reinterpret_cast<const uint4*>(sp);
+            __builtin_memcpy(dp, &v, 16);
         } else {
             for (uint32_t i = 0; i < nbytes; ++i) dp[i] = sp[i];
         }
@@ -388,15 +391,19 @@ __device__ __forceinline__ uint32_t stream_load_dword(const uint8_t* base, uint3
     asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
     return v;
 }
-template <bool XDELTA>
-__device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t q, ItemRegs& R) {
+// RAGGED (ns not a multiple of 16): the last group of a block's last tile is short; its missing rows re-read the last
+// valid one (the transform masks them), so that no load leaves the block.  `tn` = samples in the tile.
+template <bool XDELTA, bool RAGGED>
+__device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t tn, uint32_t q,
+                                                 ItemRegs& R) {
     const uint32_t rstride = g.nch * 4u;
     const uint32_t grp = fast_div(q, g.nch, m_nch);
     const uint32_t c = q - grp * g.nch;
     const uint32_t t = s0 + (grp << 4);
     const uint32_t off = (t * g.nch + c) * 4u;  // (block_bytes < 4 GiB: the host checks)
+    const uint32_t last = RAGGED ? (min(16u, tn - (grp << 4)) - 1u) * rstride : 0u;
 #pragma unroll
-    for (uint32_t e = 0; e < 16; ++e) R.pv[e] = stream_load_dword(blk, off + e * rstride);
+    for (uint32_t e = 0; e < 16; ++e) R.pv[e] = stream_load_dword(blk, off + (RAGGED ? min(e * rstride, last) : e * rstride));
     if (XDELTA) {
         // channel start: the flat array continues from the end of channel c-1 (flat index 0: patched by the consumer)
         const uint32_t cm = c ? c - 1 : 0u;
@@ -420,7 +427,7 @@ __device__ __forceinline__ void item_wait(ItemRegs& R) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool XDELTA>
+template <bool XDELTA, bool RAGGED>
 __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
@@ -439,26 +446,28 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         return wk;
     };
     auto tile_s0 = [&](uint32_t wk) { return (wk - (wk / tiles_per_block) * tiles_per_block) * T; };
-    auto tile_items = [&](uint32_t s0_) { return g.nch * (min(T, g.ns - s0_) >> 4); };  // (ns % 16 == 0)
+    auto tile_items = [&](uint32_t s0_) { return g.nch * ((min(T, g.ns - s0_) + 15u) >> 4); };
 
     // ---- load side of the stream: tile lw, ordinal lj of its l_ipt ----
-    uint32_t lw = skip_untouched(blockIdx.x), lj = 0, l_s0 = 0, l_nitems = 1, l_ipt = 0xFFFFFFFFu;
+    uint32_t lw = skip_untouched(blockIdx.x), lj = 0, l_s0 = 0, l_tn = 16, l_nitems = 1, l_ipt = 0xFFFFFFFFu;
     const uint8_t* l_blk = src;
     auto l_open = [&]() {
         if (lw < total) {
             l_s0 = tile_s0(lw);
+            l_tn = min(T, g.ns - l_s0);
             l_nitems = tile_items(l_s0);
             l_ipt = (l_nitems + nthr - 1) / nthr;
             l_blk = src + (size_t)(lw / tiles_per_block) * g.block_bytes;
         } else {  // out of tiles: keep the ring turning on item 0 of block 0
             l_s0 = 0;
+            l_tn = 16;
             l_nitems = 1;
             l_ipt = 0xFFFFFFFFu;
             l_blk = src;
         }
     };
     auto fetch = [&](ItemRegs& R) __attribute__((always_inline)) {
-        load_item_stream<XDELTA>(l_blk, g, m_nch, l_s0, min(tid + lj * nthr, l_nitems - 1), R);
+        load_item_stream<XDELTA, RAGGED>(l_blk, g, m_nch, l_s0, l_tn, min(tid + lj * nthr, l_nitems - 1), R);
         if (++lj == l_ipt) {
             lw = skip_untouched(lw + gridDim.x);
             lj = 0;
@@ -525,9 +534,9 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             if (f && !(ablate & 131072u)) atomicOr(&needmask[tc.b], f);
         }
         // plane rows -> HBM: 16-byte units, T contiguous bytes per (plane, channel)
-        const uint32_t upr = tc.Tn >> 4;
+        const uint32_t upr = (tc.Tn + 15u) >> 4;
         const uint32_t nunits = kcount * g.nch * upr;
-        const bool whole_lines = (upr & 7u) == 0 && !(ablate & (1u << 21));  // rows are whole 128-byte lines (else: store everything)
+        const bool whole_lines = (upr & 7u) == 0 && (tc.Tn & 15u) == 0 && !(ablate & (1u << 21));  // rows are whole 128-byte lines (else: store everything)
         const uint32_t m_upr = magic_of(upr);
         for (uint32_t u = tid; u < nunits; u += nthr) {
             const uint32_t row = fast_div(u, upr, m_upr);  // (k-kfirst)*nch + c
@@ -546,7 +555,17 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
                 const uint32_t bucket = ((c * g.ns + tc.s0 + colu * 16) >> 16) >> dirty_shift;
                 if (!((s_nz[8 * g.nch + 1 + kr * 4 + (bucket >> 5)] >> (bucket & 31u)) & 1u)) continue;
             }
-            *reinterpret_cast<uint4*>(dp) = v;
+            if (!RAGGED) {
+                *reinterpret_cast<uint4*>(dp) = v;
+            } else {
+                // rows start at c * ns: any byte alignment (the hardware takes unaligned 16-byte stores); the row's last unit may be short
+                const uint32_t nbytes = min(16u, tc.Tn - colu * 16);
+                if (nbytes == 16) {
+                    __builtin_memcpy(dp, &v, 16);
+                } else {
+                    for (uint32_t i = 0; i < nbytes; ++i) dp[i] = sp[i];
+                }
+            }
         }
     };
     // one turn of the ring for set R; true when the stream's last tile has been stored
@@ -784,8 +803,10 @@ INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
-template __global__ void k_tile_stream<true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
-template __global__ void k_tile_stream<false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 
