@@ -12,7 +12,7 @@ usage: hbm_traffic.py <fetch_dir> <write_dir> [out.json]"""
 import collections, csv, glob, json, os, sys
 
 STAGES = {
-    "preprocess": ["k_tile_planes", "k_planar_planes", "k_tile_planar", "k_fwht", "k_dct"],
+    "preprocess": ["k_tile_stream", "k_tile_planes", "k_planar_planes", "k_tile_planar", "k_fwht", "k_dct"],
     "nb_scan": ["k_nb_scan"],
     "hzr_hist": ["k_hist"],
     "hzr_tree": ["k_tree"],
