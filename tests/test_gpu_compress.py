@@ -237,3 +237,36 @@ def test_plane_workspace_carries_nothing_between_calls(api, orc, ns):
     one = _plane_mix(nch, ns, 999, "spikes")
     assert pk.compress(one) == po.compress(one)
     pk.close()
+
+
+def test_front_end_shape_fuzz(api, orc):
+    """Random int32 geometries through the streaming front end (k_tile_stream): channel counts on both sides of the wave
+    width, ns with and without whole 16-sample groups, tiles with fewer items than threads, several tiles per block,
+    batches that escalate nb in the middle (fix-up pass) -- every stream against the oracle, batch after batch on the
+    same handle (the plane workspace persists)."""
+    import torch
+
+    r = np.random.default_rng(20251)
+    shapes = [(1, 16), (1, 17), (2, 31), (3, 4097), (7, 1000), (12, 8192), (12, 3419), (31, 260), (64, 513), (65, 400), (100, 129), (130, 48),
+              (5, 70001), (64, 2048), (20, 16384)]
+    for kind in ("xdelta_hzr", "hzr"):
+        for nch, ns in shapes:
+            nb0 = int(r.integers(1, 4)) if kind == "xdelta_hzr" else int(r.integers(1, 5))
+            po = orc.packer(kind, 4, nch, ns, nb0)
+            pk = api.SignalPacker(kind, 4, nch, ns, nb0)
+            for call in range(2):
+                B = int(r.integers(1, 5))
+                amps = [int(r.choice([3, 60, 1 << 10, 1 << 14, 1 << 21, 1 << 29])) for _ in range(B)]
+                blocks = [cases._rand_native(nch, ns, 4, int(r.integers(1 << 30)), a, walk=bool(r.integers(2))) for a in amps]
+                d_src = torch.from_numpy(np.stack(blocks)).cuda()
+                d_dst, d_sizes = pk.compress_batch(d_src)
+                torch.cuda.synchronize()
+                sizes = d_sizes.cpu().numpy()
+                out = d_dst.cpu().numpy()
+                for i, blk in enumerate(blocks):
+                    want = po.compress(blk)
+                    got = out[i, : sizes[i]].tobytes()
+                    assert got == want, "%s %dx%d call %d block %d amp %d: %s" % (kind, nch, ns, call, i, amps[i], describe_mismatch(got, want))
+                if kind == "xdelta_hzr":
+                    assert pk.nb == orc.packer_nb(po)
+            pk.close()
