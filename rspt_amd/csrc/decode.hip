@@ -39,8 +39,9 @@ __device__ __forceinline__ const uint8_t* stream_base(const uint8_t* src, uint64
 
 __global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride_in, uint32_t nblocks, Geom g, const uint32_t* __restrict__ nb_state,
                             uint64_t* __restrict__ blk_off, uint64_t* __restrict__ consumed, uint8_t* __restrict__ means,
-                            const uint64_t* __restrict__ pidx) {
+                            const uint64_t* __restrict__ pidx, uint32_t* __restrict__ dec_counter) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) *dec_counter = 0;  // k_dec_block's work queue
     const uint32_t b = t / kMaxPlanes, k = t % kMaxPlanes;
     if (b >= nblocks) return;
     const uint32_t nb = *nb_state;
@@ -231,20 +232,22 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
     return bp;
 }
 
-__global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
-                                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
-                                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
-                                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
-                                                          const uint64_t* __restrict__ pidx) {
-    __shared__ DecLds d;
-    // workgroup -> hzr block, plane-major (grid.x = blocks * nblk, grid.y = plane): with the plane fastest the dense
-    // plane-0 blocks would all land on the XCDs 0 and 4 (workgroup i goes to XCD i % 8)
-    const uint32_t k = blockIdx.y, j = blockIdx.x % g.nblk, b = blockIdx.x / g.nblk;
+__shared__ DecLds g_dec;
+
+// one hzr block (plane k, block j of stream b) by one 1024-thread workgroup
+__device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, const uint8_t* __restrict__ src, uint64_t src_stride, const Geom& g,
+                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
+                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
+                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
+                                          const uint64_t* __restrict__ pidx) {
+    DecLds& d = g_dec;
     if (k >= *nb_state) return;
     const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint32_t hb = hb_index(g, b, k, j);
 #define DEC_STAMP(i) do { if (stamps && tid == 0 && hb < 512u) stamps[hb * 8u + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     DEC_STAMP(0);
+    // diagnostic: wall-clock (100 MHz) start/end of every workgroup, for a concurrency census (tools/census_decode.py)
+    if (stamps && tid == 0 && hb < 16384u) stamps[65536u + 2u * hb] = __builtin_amdgcn_s_memrealtime();
     const uint64_t off = blk_off[hb];
     if (off == ~0ull) return;
     uint64_t lim_unused;
@@ -557,7 +560,28 @@ __global__ __launch_bounds__(kDecThreads) void k_dec_block(const uint8_t* __rest
     const uint32_t bad = (e2 || total != out_size) ? 1u : 0u;
     if (__syncthreads_or((int)bad) && tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
     DEC_STAMP(6);
+    if (stamps && tid == 0 && hb < 16384u) stamps[65536u + 2u * hb + 1u] = __builtin_amdgcn_s_memrealtime();
 #undef DEC_STAMP
+}
+
+// Persistent grid over the hzr blocks, plane-major (the dense plane-0 blocks first): the first block of a workgroup is
+// static, the rest come from a counter.
+__global__ __launch_bounds__(kDecThreads, 8) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
+                                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
+                                                          uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
+                                                          unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
+                                                          const uint64_t* __restrict__ pidx, uint32_t* __restrict__ counter, uint32_t total) {
+    __shared__ uint32_t s_next;
+    const uint32_t per_plane = total / kMaxPlanes;  // blocks * nblk
+    for (uint32_t pass = 0;; ++pass) {
+        __syncthreads();  // everyone is done with the previous block's LDS (and with s_next)
+        if (threadIdx.x == 0) s_next = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t i = s_next;
+        if (i >= total) break;
+        const uint32_t k = i / per_plane, x = i - k * per_plane;
+        dec_block(k, x % g.nblk, x / g.nblk, src, src_stride, g, nb_state, blk_off, planes, consumed, stamps, vcc, pidx);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -125,7 +125,7 @@ struct rspt_hip_packer {
     uint32_t* plane_dirty = nullptr;  // [cap*4][4]
     uint32_t dirty_shift = 0;
     bool planes_unknown = false;      // something else (decompress, a diagnostic run) wrote the planes: flag them all
-    uint32_t* nb_state = nullptr;  // [1] persistent
+    uint32_t* nb_state = nullptr;  // [4] persistent: [0] = nb; [2] = work counter of the decoder's persistent grid (zeroed by k_dec_frame)
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
     uint32_t* seghist = nullptr;   // [cap*4*nblk][16][264] u16: tokens starting in each 4 KiB segment (k_hist -> k_tree)
     uint32_t* zbza = nullptr;      // [cap*4*nblk][4096] zeros before | after << 16 of every 16-byte granule (k_hist -> k_encode)
@@ -454,7 +454,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     static CrcConsts cc;  // ~87 KB: keep it off the stack
     make_crc_consts(cc);
     p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, sizeof(uint32_t)) != hipSuccess ||
+    if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -847,9 +847,15 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         const uint8_t* src = (const uint8_t*)d_src;
         HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
-                           d_consumed, p->means, pidx);
-        hipLaunchKernelGGL(k_dec_block, dim3(g.nblk * B, kMaxPlanes), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off, p->planes,
-                           d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr, pidx);
+                           d_consumed, p->means, pidx, p->nb_state + 2);
+        {
+            // persistent: block costs differ 10x (dense plane 0 against light planes) and the dispatcher places workgroup i
+            // on XCD i % 8 in order, so a plain grid ran its second half at a quarter of the slots (tools/census_decode.py)
+            const uint32_t total = g.nblk * B * kMaxPlanes;
+            const uint32_t want = 2u * (uint32_t)p->num_cu;  // two 1024-thread workgroups (76 KiB of LDS each) per CU
+            hipLaunchKernelGGL(k_dec_block, dim3(want < total ? want : total), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off,
+                               p->planes, d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr, pidx, p->nb_state + 2, total);
+        }
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
         if (xd) {
