@@ -156,6 +156,135 @@ __global__ __launch_bounds__(1024) void k_fwht(int32_t* __restrict__ planar, Geo
 constexpr int kDctCh = 4;
 constexpr uint32_t kDctChunk = 1024;
 
+// ---- 65536-point rows: the whole row lives in registers --------------------------------------------------------------
+// The stages (lo,hi) -> (lo+hi, lo-hi) act on one index bit each and commute exactly in wrap-around arithmetic, so the
+// 16 of them are taken as three groups of index bits, each group inside the registers of a thread (64 values = 6 bits):
+//   layout 1   regs = bits {15..12, 1, 0}   thread = bits 11..2     (16-byte loads, 1 KiB per wave instruction)
+//   layout 2   regs = bits 7..2             thread = bits {15..12, 11..8, 1..0}
+//   layout 3   regs = bits {11..8, 1, 0}    thread = bits {15..12, 7..2}   (16-byte stores, 1 KiB per wave instruction)
+// with two transposes through a 128 KiB LDS image, one half of the row (bit 15) at a time.  The row is read once and
+// written once (k_fwht's general form reads it three times: the sum, then both halves for each half).  Element i' of a
+// half sits at word i' ^ (((i' >> 8) & 7) << 2): 16-byte accesses by consecutive lanes stay conflict-free (the flipped
+// bits are constant within an instruction), and the dword accesses of layout 2 -- lanes 4 words apart in blocks 256
+// words apart -- spread over all 32 banks.
+__device__ __forceinline__ uint32_t fwht_swz(uint32_t a) { return a ^ (((a >> 8) & 7u) << 2); }
+
+template <int NBITS_LO, int NBITS>
+__device__ __forceinline__ void fwht_regs(uint32_t (&v)[64]) {  // butterflies over register-index bits [NBITS_LO, NBITS)
+#pragma unroll
+    for (int d = 1 << NBITS_LO; d < (1 << NBITS); d <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if (!(i & d)) {
+                const uint32_t x = v[i], y = v[i + d];
+                v[i] = x + y;
+                v[i + d] = x - y;
+            }
+        }
+    }
+}
+
+template <bool FORWARD>
+__global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, Geom g, uint8_t* __restrict__ means) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sh_i[];
+    uint32_t* sh = reinterpret_cast<uint32_t*>(sh_i);
+    __shared__ long long s_red[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = blockIdx.x, b = blockIdx.y;
+    constexpr uint32_t n = 65536u, k = 16u;
+    int32_t* row = planar + (size_t)b * g.N + (size_t)c * n;
+
+    uint32_t v[64];  // layout 1: v[4 q + e] = row[4096 q + 4 tid + e]
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        const uint4 x = reinterpret_cast<const uint4*>(row)[q * 1024 + tid];
+        v[4 * q] = x.x;
+        v[4 * q + 1] = x.y;
+        v[4 * q + 2] = x.z;
+        v[4 * q + 3] = x.w;
+    }
+    int32_t mean;
+    if (FORWARD) {
+        long long sum = 0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) sum += (int32_t)v[i];
+        sum = wave_add_i64(sum);
+        if ((tid & 63u) == 0) s_red[tid >> 6] = sum;
+        __syncthreads();
+        long long t = 0;
+        for (uint32_t i = 0; i < 16; ++i) t += s_red[i];
+        mean = mean_from_sum(t, n);
+        if (tid == 0) store_mean_hdr(means, g, b, c, mean);
+    } else {
+        mean = load_mean_hdr(means, g, b, c);
+    }
+    fwht_regs<0, 6>(v);  // bits 0, 1, 12..15
+
+    // transpose 1: layout 1 -> layout 2
+    uint32_t w[64];
+    const uint32_t half = tid >> 9;  // bit 15 of the elements this thread holds in layouts 2 and 3
+    const uint32_t base2 = (((tid >> 6) & 7u) << 12) | (((tid >> 2) & 15u) << 8) | (tid & 3u);
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+#pragma unroll
+        for (uint32_t qq = 0; qq < 8; ++qq) {
+            const uint32_t q = h * 8 + qq;
+            *reinterpret_cast<uint4*>(&sh[fwht_swz((qq << 12) | (tid << 2))]) = make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
+        __syncthreads();
+        if (half == h) {
+#pragma unroll
+            for (uint32_t r = 0; r < 64; ++r) w[r] = sh[fwht_swz(base2 | (r << 2))];
+        }
+        __syncthreads();
+    }
+    fwht_regs<0, 6>(w);  // bits 2..7
+
+    // transpose 2: layout 2 -> layout 3 (each half: written and read by the same 512 threads)
+    uint32_t u[64];
+    const uint32_t base3 = (((tid >> 6) & 7u) << 12) | ((tid & 63u) << 2);
+#pragma unroll
+    for (uint32_t h = 0; h < 2; ++h) {
+        if (half == h) {
+#pragma unroll
+            for (uint32_t r = 0; r < 64; ++r) sh[fwht_swz(base2 | (r << 2))] = w[r];
+        }
+        __syncthreads();
+        if (half == h) {
+#pragma unroll
+            for (uint32_t pp = 0; pp < 16; ++pp) {
+                const uint4 x = *reinterpret_cast<const uint4*>(&sh[fwht_swz(base3 | (pp << 8))]);
+                u[4 * pp] = x.x;
+                u[4 * pp + 1] = x.y;
+                u[4 * pp + 2] = x.z;
+                u[4 * pp + 3] = x.w;
+            }
+        }
+        __syncthreads();
+    }
+    fwht_regs<2, 6>(u);  // bits 8..11 (register-index bits 2..5; bits 0, 1 of the index are done)
+
+    const uint32_t i0 = ((tid >> 6) << 12) | ((tid & 63u) << 2);  // bits 15..12 and 7..2
+#pragma unroll
+    for (uint32_t pp = 0; pp < 16; ++pp) {
+        const uint32_t idx = i0 | (pp << 8);
+        uint32_t o[4];
+#pragma unroll
+        for (uint32_t e = 0; e < 4; ++e) {
+            int32_t y = (int32_t)u[4 * pp + e];
+            if (FORWARD) {
+                // WHT(x - m) = WHT(x) - m*n*delta_0 (exact mod 2^32); fwht_normalize (fwht.c:30-34): truncation toward zero
+                if (idx + e == 0) y = (int32_t)((uint32_t)y - (uint32_t)mean * n);
+                y = (y + ((y >> 31) & (int32_t)(n - 1))) >> k;
+            } else {
+                y = (int32_t)((uint32_t)y + (uint32_t)mean);
+            }
+            o[e] = (uint32_t)y;
+        }
+        *reinterpret_cast<uint4*>(row + idx) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void k_dct(const int32_t* __restrict__ in, Geom g, uint8_t* __restrict__ means,
                                             const float* __restrict__ tab, double scale0, double scale1, float cs0,
@@ -385,6 +514,8 @@ template __global__ void k_dctfft_rows<false>(const double2*, Geom, const uint8_
 
 template __global__ void k_fwht<true>(int32_t*, Geom, uint8_t*);
 template __global__ void k_fwht<false>(int32_t*, Geom, uint8_t*);
+template __global__ void k_fwht64k<true>(int32_t*, Geom, uint8_t*);
+template __global__ void k_fwht64k<false>(int32_t*, Geom, uint8_t*);
 template __global__ void k_dct<true>(const int32_t*, Geom, uint8_t*, const float*, double, double, float, int32_t*);
 template __global__ void k_dct<false>(const int32_t*, Geom, uint8_t*, const float*, double, double, float, int32_t*);
 
