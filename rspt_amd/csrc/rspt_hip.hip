@@ -657,14 +657,14 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     if (g.kind == RSPT_HIP_KIND_HADAMARD) {
         // per channel: mean removal, WHT, truncating /n (signal_packer_hadamard.cpp:57-72)
         const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
-        if (g.ns == 65536u) {  // the whole row in registers: read once, written once
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-            hipLaunchKernelGGL((k_fwht64k<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
+        if (g.ns == 65536u) {  // the whole row in registers: read once, and the byte planes written straight from them
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+            hipLaunchKernelGGL((k_fwht64k<true, true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means, p->planes, p->nzflag, 3u);
         } else {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
             hipLaunchKernelGGL((k_fwht<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
+            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
         }
-        hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
         if (p->dct_fft) {
             hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
@@ -876,8 +876,9 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         if (g.kind == RSPT_HIP_KIND_HADAMARD) {
             const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
             if (g.ns == 65536u) {
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
-                hipLaunchKernelGGL((k_fwht64k<false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
+                hipLaunchKernelGGL((k_fwht64k<false, false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means, (uint8_t*)nullptr,
+                                   (uint32_t*)nullptr, 0u);
             } else {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
                 hipLaunchKernelGGL((k_fwht<false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);

@@ -184,8 +184,11 @@ __device__ __forceinline__ void fwht_regs(uint32_t (&v)[64]) {  // butterflies o
     }
 }
 
-template <bool FORWARD>
-__global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, Geom g, uint8_t* __restrict__ means) {
+// PLANES (compress): the normalised coefficients leave as byte planes + non-zero map straight away (what k_planar_planes
+// would do in another pass over HBM); a wave's 4096 outputs are exactly one 4 KiB segment of every plane.
+template <bool FORWARD, bool PLANES>
+__global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, Geom g, uint8_t* __restrict__ means, uint8_t* __restrict__ planes,
+                                                 uint32_t* __restrict__ nzflag, uint32_t nplanes) {
     extern __shared__ __attribute__((aligned(16))) int32_t sh_i[];
     uint32_t* sh = reinterpret_cast<uint32_t*>(sh_i);
     __shared__ long long s_red[16];
@@ -265,6 +268,7 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
     fwht_regs<2, 6>(u);  // bits 8..11 (register-index bits 2..5; bits 0, 1 of the index are done)
 
     const uint32_t i0 = ((tid >> 6) << 12) | ((tid & 63u) << 2);  // bits 15..12 and 7..2
+    uint32_t nzk[4] = {0, 0, 0, 0};
 #pragma unroll
     for (uint32_t pp = 0; pp < 16; ++pp) {
         const uint32_t idx = i0 | (pp << 8);
@@ -281,7 +285,27 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
             }
             o[e] = (uint32_t)y;
         }
-        *reinterpret_cast<uint4*>(row + idx) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (!PLANES) {
+            *reinterpret_cast<uint4*>(row + idx) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            // 4 x 4 byte transpose (preprocess.hip: transform_item): one dword per plane
+            const uint32_t lo01 = __builtin_amdgcn_perm(o[1], o[0], 0x05010400u), hi01 = __builtin_amdgcn_perm(o[1], o[0], 0x07030602u);
+            const uint32_t lo23 = __builtin_amdgcn_perm(o[3], o[2], 0x05010400u), hi23 = __builtin_amdgcn_perm(o[3], o[2], 0x07030602u);
+            const uint32_t pl[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
+                                    __builtin_amdgcn_perm(hi23, hi01, 0x05040100u), __builtin_amdgcn_perm(hi23, hi01, 0x07060302u)};
+#pragma unroll
+            for (uint32_t kk = 0; kk < 4; ++kk) {
+                if (kk < nplanes) {
+                    *reinterpret_cast<uint32_t*>(planes + ((size_t)b * kMaxPlanes + kk) * g.plane_stride + (size_t)c * n + idx) = pl[kk];
+                    nzk[kk] |= pl[kk];
+                }
+            }
+        }
+    }
+    if (PLANES) {
+        const uint32_t flat = c * n + i0;  // this wave's outputs: [flat & ~4095, +4096)
+        for (uint32_t kk = 0; kk < nplanes; ++kk)
+            if (__ballot(nzk[kk] != 0) && (tid & 63u) == 0) atomicOr(&nzflag[hb_index(g, b, kk, flat >> 16)], 1u << ((flat >> 12) & 15u));
     }
 }
 
@@ -514,8 +538,8 @@ template __global__ void k_dctfft_rows<false>(const double2*, Geom, const uint8_
 
 template __global__ void k_fwht<true>(int32_t*, Geom, uint8_t*);
 template __global__ void k_fwht<false>(int32_t*, Geom, uint8_t*);
-template __global__ void k_fwht64k<true>(int32_t*, Geom, uint8_t*);
-template __global__ void k_fwht64k<false>(int32_t*, Geom, uint8_t*);
+template __global__ void k_fwht64k<true, true>(int32_t*, Geom, uint8_t*, uint8_t*, uint32_t*, uint32_t);
+template __global__ void k_fwht64k<false, false>(int32_t*, Geom, uint8_t*, uint8_t*, uint32_t*, uint32_t);
 template __global__ void k_dct<true>(const int32_t*, Geom, uint8_t*, const float*, double, double, float, int32_t*);
 template __global__ void k_dct<false>(const int32_t*, Geom, uint8_t*, const float*, double, double, float, int32_t*);
 
