@@ -624,9 +624,11 @@ template <bool XDELTA>
 __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict__ planar, Geom g, uint32_t nplanes,
                                                        uint8_t* __restrict__ planes, uint32_t* __restrict__ nzflag) {
     const uint32_t b = blockIdx.y;
-    if (!XDELTA) {
-        // No neighbour dependence: fully coalesced form.  A wave takes 1024 consecutive elements (one KiB of every plane);
-        // in each of four rounds lane l loads elements [256 q + 4 l, +4) as 16 bytes and stores one dword per plane.
+    {
+        // Fully coalesced form.  A wave takes 1024 consecutive elements (one KiB of every plane); in each of four rounds
+        // lane l loads elements [256 q + 4 l, +4) as 16 bytes and stores one dword per plane.  XDELTA: element i needs
+        // p[i-1], p[i-2] -- the previous lane's last two values (DPP shift), for lane 0 the previous round's lane 63 or the
+        // two elements in front of the wave.
         const uint32_t wbase = (blockIdx.x * 256 + (threadIdx.x & ~63u)) * 16;  // first element of this wave
         const int32_t* pw_ = planar + (size_t)b * g.N;
         if (wbase + 1024 <= g.N && (reinterpret_cast<uintptr_t>(pw_ + wbase) & 15u) == 0) {
@@ -634,10 +636,29 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
             uint4 v[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4*>(pw_ + wbase)[q * 64 + l];
+            uint32_t front1 = 0, front2 = 0;  // p[wbase-1], p[wbase-2] (the flat array starts from zeros)
+            if (XDELTA && wbase) {
+                front1 = (uint32_t)pw_[wbase - 1];
+                front2 = (uint32_t)pw_[wbase - 2];
+            }
             uint32_t nzk[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t a0 = v[q].x, a1 = v[q].y, a2 = v[q].z, a3 = v[q].w;
+                uint32_t a0 = v[q].x, a1 = v[q].y, a2 = v[q].z, a3 = v[q].w;
+                if (XDELTA) {
+                    uint32_t pm1 = dpp<0x138>(0u, a3), pm2 = dpp<0x138>(0u, a2);  // wave_shr:1
+                    if (l == 0) {
+                        pm1 = q ? read_lane(v[q ? q - 1 : 0].w, 63) : front1;
+                        pm2 = q ? read_lane(v[q ? q - 1 : 0].z, 63) : front2;
+                    }
+                    const bool first = (wbase | q | l) == 0;  // flat index 0: delta_encode and xor_encode_32 start from 0
+                    const uint32_t om1 = first ? 0u : pm1 - pm2 - 128u;
+                    const uint32_t o0 = a0 - (first ? 0u : pm1) - 128u, o1 = a1 - a0 - 128u, o2 = a2 - a1 - 128u, o3 = a3 - a2 - 128u;
+                    a0 = o0 ^ om1;
+                    a1 = o1 ^ o0;
+                    a2 = o2 ^ o1;
+                    a3 = o3 ^ o2;
+                }
                 const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
                 const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
                 const uint32_t pl[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
