@@ -264,11 +264,12 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
                    lds_r = ((uint32_t)sizeof(double2) << (l2 + lr)) + ((uint32_t)sizeof(double2) << (l2 - 1));  // points + stage twiddles
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_cols<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_rows<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+    const uint32_t fthr = 1024;  // 4096 points per workgroup: 256 threads (4 waves) left the LDS passes latency-bound (34 -> 46 GS/s)
     for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
         const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
-        hipLaunchKernelGGL((k_dctfft_cols<FORWARD>), dim3(1u << (l2 - lw), g.nch, nbk), dim3(256), lds_c, st, in, g, p->mean_i32, p->fft_tw,
+        hipLaunchKernelGGL((k_dctfft_cols<FORWARD>), dim3(1u << (l2 - lw), g.nch, nbk), dim3(fthr), lds_c, st, in, g, p->mean_i32, p->fft_tw,
                            p->fft_post, p->fft_scratch, l1, l2, b0, p->dct_cs0);
-        hipLaunchKernelGGL((k_dctfft_rows<FORWARD>), dim3(1u << (l1 - lr), g.nch, nbk), dim3(256), lds_r, st, p->fft_scratch, g, p->means,
+        hipLaunchKernelGGL((k_dctfft_rows<FORWARD>), dim3(1u << (l1 - lr), g.nch, nbk), dim3(fthr), lds_r, st, p->fft_scratch, g, p->means,
                            p->fft_tw, p->fft_post, out, l1, l2, b0, FORWARD ? p->dct_scale0 : 0.0, FORWARD ? p->dct_scale1 : p->idct_scale);
     }
 }

@@ -414,19 +414,44 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return _
 // otherwise wait on a global load each).
 __device__ __forceinline__ void lds_fft(double2* sh, const double2* stw, uint32_t logn, uint32_t lw, bool inverse) {
     const uint32_t W = 1u << lw;
+    auto mul = [&](const double2& x, const double2& w) -> double2 {  // x * (w.x + i ws), ws = -/+ w.y
+        const double ws = inverse ? w.y : -w.y;
+        return make_double2(x.x * w.x - x.y * ws, x.x * ws + x.y * w.x);
+    };
+    uint32_t s = 1;
+    // two stages at a time on four points in registers (half the LDS passes and barriers): stage s pairs (p0,p1), (p2,p3)
+    // with twiddle index m; stage s+1 pairs (p0,p2) with m and (p1,p3) with m + half
+    const uint32_t nq = (1u << (logn - 2)) << lw;
+    for (; s + 1 <= logn; s += 2) {
+        const uint32_t half = 1u << (s - 1);
+        for (uint32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            const uint32_t col = q & (W - 1), gq = q >> lw;
+            const uint32_t m = gq & (half - 1);
+            const uint32_t i0 = ((gq >> (s - 1)) << (s + 1)) + m;
+            const double2 w1 = stw[m << (logn - s)], w2 = stw[m << (logn - s - 1)], w3 = stw[(m + half) << (logn - s - 1)];
+            double2 p0 = sh[i0 * W + col], p1 = sh[(i0 + half) * W + col], p2 = sh[(i0 + 2 * half) * W + col], p3 = sh[(i0 + 3 * half) * W + col];
+            const double2 t1 = mul(p1, w1), t3 = mul(p3, w1);
+            const double2 a0 = make_double2(p0.x + t1.x, p0.y + t1.y), a1 = make_double2(p0.x - t1.x, p0.y - t1.y);
+            const double2 a2 = make_double2(p2.x + t3.x, p2.y + t3.y), a3 = make_double2(p2.x - t3.x, p2.y - t3.y);
+            const double2 u2 = mul(a2, w2), u3 = mul(a3, w3);
+            sh[i0 * W + col] = make_double2(a0.x + u2.x, a0.y + u2.y);
+            sh[(i0 + 2 * half) * W + col] = make_double2(a0.x - u2.x, a0.y - u2.y);
+            sh[(i0 + half) * W + col] = make_double2(a1.x + u3.x, a1.y + u3.y);
+            sh[(i0 + 3 * half) * W + col] = make_double2(a1.x - u3.x, a1.y - u3.y);
+        }
+        __syncthreads();
+    }
     const uint32_t nbf = (1u << (logn - 1)) << lw;
-    for (uint32_t s = 1; s <= logn; ++s) {
+    for (; s <= logn; ++s) {  // (odd logn: the last stage alone)
         const uint32_t half = 1u << (s - 1);
         for (uint32_t q = threadIdx.x; q < nbf; q += blockDim.x) {
             const uint32_t col = q & (W - 1), bf = q >> lw;
             const uint32_t m = bf & (half - 1);
             const uint32_t i0 = ((bf >> (s - 1)) << s) + m;
-            const double2 w = stw[m << (logn - s)];
-            const double ws = inverse ? w.y : -w.y;
-            const double2 a = sh[i0 * W + col], bq = sh[(i0 + half) * W + col];
-            const double tr = bq.x * w.x - bq.y * ws, ti = bq.x * ws + bq.y * w.x;
-            sh[i0 * W + col] = make_double2(a.x + tr, a.y + ti);
-            sh[(i0 + half) * W + col] = make_double2(a.x - tr, a.y - ti);
+            const double2 a = sh[i0 * W + col];
+            const double2 t = mul(sh[(i0 + half) * W + col], stw[m << (logn - s)]);
+            sh[i0 * W + col] = make_double2(a.x + t.x, a.y + t.y);
+            sh[(i0 + half) * W + col] = make_double2(a.x - t.x, a.y - t.y);
         }
         __syncthreads();
     }
@@ -440,7 +465,7 @@ __device__ __forceinline__ void load_stage_twiddles(double2* stw, const double2*
 constexpr uint32_t kFftLdsLog = 12;  // 4096 complex fp64 points (64 KiB) per workgroup
 
 template <bool FORWARD>
-__global__ __launch_bounds__(256) void k_dctfft_cols(const int32_t* __restrict__ in, Geom g, const int32_t* __restrict__ mean_i32,
+__global__ __launch_bounds__(1024) void k_dctfft_cols(const int32_t* __restrict__ in, Geom g, const int32_t* __restrict__ mean_i32,
                                                     const double2* __restrict__ tw, const double2* __restrict__ post,
                                                     double2* __restrict__ scratch, uint32_t l1, uint32_t l2, uint32_t b0, float cs0) {
     extern __shared__ __attribute__((aligned(16))) double2 shf[];
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) void k_dctfft_cols(const int32_t* __restrict__
 }
 
 template <bool FORWARD>
-__global__ __launch_bounds__(256) void k_dctfft_rows(const double2* __restrict__ scratch, Geom g, const uint8_t* __restrict__ means,
+__global__ __launch_bounds__(1024) void k_dctfft_rows(const double2* __restrict__ scratch, Geom g, const uint8_t* __restrict__ means,
                                                     const double2* __restrict__ tw, const double2* __restrict__ post,
                                                     int32_t* __restrict__ out, uint32_t l1, uint32_t l2, uint32_t b0, double scale0,
                                                     double scale1) {
