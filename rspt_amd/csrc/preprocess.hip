@@ -763,7 +763,10 @@ __global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__
 
 // The common shape of the same conversion -- int32 samples, nch % 4 == 0, ns % 4 == 0, 16-byte aligned input -- with 16-byte
 // global accesses on both sides and no division per element (the mirror image of decode.hip: k_planar_native_i32x4).
-__global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __restrict__ src, Geom g, uint32_t T4, int32_t* __restrict__ planar) {
+// row_sum (optional): [block][channel] int64 sums of the samples, accumulated tile by tile (the dct's channel means without
+// a second pass over the block)
+__global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __restrict__ src, Geom g, uint32_t T4, int32_t* __restrict__ planar,
+                                                          long long* __restrict__ row_sum) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     int32_t* tile = reinterpret_cast<int32_t*>(lds);  // [nch][T4+1]
     const uint32_t tid = threadIdx.x, b = blockIdx.y;
@@ -789,6 +792,15 @@ __global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __rest
         }
     }
     __syncthreads();
+    if (row_sum) {  // four threads per channel row, one 64-bit atomic per (tile, channel)
+        for (uint32_t c = tid >> 2; c < g.nch; c += 64) {
+            long long sm = 0;
+            for (uint32_t t = tid & 3u; t < Tn; t += 4) sm += tile[c * RS + t];
+            sm += __shfl_xor(sm, 1);
+            sm += __shfl_xor(sm, 2);
+            if ((tid & 3u) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(row_sum + (size_t)b * g.nch + c), (unsigned long long)sm);
+        }
+    }
     {
         const uint32_t qpr = Tn >> 2;  // 16-byte pieces per channel row
         const uint32_t step_c = 256u / qpr, step_t = 256u - step_c * qpr;

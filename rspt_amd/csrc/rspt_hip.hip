@@ -153,6 +153,8 @@ struct rspt_hip_packer {
     double2* fft_scratch = nullptr;    // [fft_bpp][nch][n]
     size_t fft_bpp = 0;                // blocks per pass (bounds the scratch to ~1 GiB)
     int32_t* mean_i32 = nullptr;       // [cap][nch]
+    long long* row_sum = nullptr;      // [blocks][nch] channel sums taken by the de-interleave pass (dct at large ns); lives in the per-call zero region
+    bool have_row_sum = false;         // this call's front end filled row_sum
     uint32_t ntile = 0;
     uint32_t Tn_native = 0;  // tile of k_planar_native
 
@@ -244,7 +246,8 @@ static uint32_t launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nb
         T4 = T4 > 1024 ? 1024 : T4 < 4 ? 4 : T4;
         if (T4 > g.ns) T4 = g.ns;
         hipLaunchKernelGGL(k_tile_planar_i32x4, dim3((g.ns + T4 - 1) / T4, (unsigned)nblocks), dim3(256), g.nch * (T4 + 1) * 4, st, d_src, g, T4,
-                           p->planar);
+                           p->planar, p->row_sum);
+        p->have_row_sum = p->row_sum != nullptr;
         return 4;
     }
     dim3 grid((g.ns + p->T - 1) / p->T, (unsigned)nblocks);
@@ -585,7 +588,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->plane_dirty, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
-    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32) * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32 + 2 * max_blocks * (size_t)g.nch + 2) * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
@@ -642,7 +645,15 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
         p->needmask = p->nzflag + nhb_call;
         p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
-        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, (size_t)((p->work_ctr + 16) - p->nzflag) * sizeof(uint32_t), st));
+        size_t zwords = (size_t)((p->work_ctr + 16) - p->nzflag);
+        p->row_sum = nullptr;
+        p->have_row_sum = false;
+        if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {  // channel sums of the de-interleave pass, 8-byte aligned behind the counters
+            zwords = (zwords + 1) & ~(size_t)1;
+            p->row_sum = reinterpret_cast<long long*>(p->nzflag + zwords);
+            zwords += 2 * nblocks * (size_t)g.nch;
+        }
+        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, zwords * sizeof(uint32_t), st));
     }
     if (p->planes_unknown || p->ablate) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave)
         HIPCHK(p, hipMemsetAsync(p->plane_dirty, 0xFF, p->cap_blocks * kMaxPlanes * 4 * sizeof(uint32_t), st));
@@ -668,7 +679,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         }
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
         if (p->dct_fft) {
-            hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
+            if (p->have_row_sum)  // the de-interleave pass summed the channels on its way: no second pass over the planar block
+                hipLaunchKernelGGL(k_means_from_sums, dim3((B * g.nch + 255) / 256), dim3(256), 0, st, p->row_sum, g, B, p->means, p->mean_i32);
+            else
+                hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
             launch_dct_fft<true>(p, B, p->planar, p->planar2, st);
         } else {
             hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,

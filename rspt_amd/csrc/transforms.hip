@@ -407,6 +407,17 @@ __global__ __launch_bounds__(1024) void k_row_means(const int32_t* __restrict__ 
     }
 }
 
+// the same from channel sums that the de-interleave pass (k_tile_planar_i32x4) has already taken
+__global__ __launch_bounds__(256) void k_means_from_sums(const long long* __restrict__ row_sum, Geom g, uint32_t nblocks, uint8_t* __restrict__ means,
+                                                        int32_t* __restrict__ mean_i32) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nblocks * g.nch) return;
+    const uint32_t b = i / g.nch, c = i - b * g.nch;
+    const int32_t m = mean_from_sum(row_sum[i], g.ns);
+    store_mean_hdr(means, g, b, c, m);
+    mean_i32[i] = m;
+}
+
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) { return __brev(v) >> (32u - bits); }
 
 // radix-2 DIT over `len = 1<<logn` points of W = 1<<lw interleaved sequences: point p of sequence q at sh[p*W + q].
