@@ -35,6 +35,7 @@ def parse_args():
     ap.add_argument("--nch", type=int, default=64)
     ap.add_argument("--ns", type=int, default=65536)
     ap.add_argument("--nb", type=int, default=3)
+    ap.add_argument("--bps", type=int, default=4, choices=[1, 2, 3, 4], help="bytes per sample of the input (the metric is quoted on 4)")
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -59,7 +60,7 @@ def cpu_baseline(args, sample_native):
     deadline = [0.0]
 
     def work(i):
-        pk = lib.packer(args.packer, 4, args.nch, args.ns, args.nb)
+        pk = lib.packer(args.packer, args.bps, args.nch, args.ns, args.nb)
         pk.compress(sample_native)  # first call pays page faults
         while time.perf_counter() < deadline[0]:
             pk.compress(sample_native)
@@ -67,7 +68,7 @@ def cpu_baseline(args, sample_native):
         pk.close()
 
     # 1 core
-    pk = lib.packer(args.packer, 4, args.nch, args.ns, args.nb)
+    pk = lib.packer(args.packer, args.bps, args.nch, args.ns, args.nb)
     pk.compress(sample_native)
     t0 = time.perf_counter()
     n1 = 0
@@ -116,10 +117,10 @@ def main():
     torch.cuda.set_device(dev)
 
     B, nch, ns = args.blocks, args.nch, args.ns
-    pk = api.SignalPacker(args.packer, 4, nch, ns, args.nb, device=local_rank)
+    pk = api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank)
     pk.reserve(B)
     # synthetic input, resident in HBM; every rank gets different blocks (SURVEY 8d generator)
-    d_src = synth.synth_batch_native(B, nch, ns, first_block=rank * B, device=dev)
+    d_src = synth.synth_batch_native(B, nch, ns, first_block=rank * B, bps=args.bps, device=dev)
     dst_stride = (pk.max_compressed_size + 255) // 256 * 256
     d_dst = [torch.empty((B, dst_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
     d_sizes = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -251,7 +252,7 @@ def main():
         achieved = alg_bytes / (acc[dominant] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        default_shape = (args.packer, B, nch, ns, args.nb) == ("xdelta_hzr", 64, 64, 65536, 3)  # what the counters were collected on
+        default_shape = (args.packer, B, nch, ns, args.nb, args.bps) == ("xdelta_hzr", 64, 64, 65536, 3, 4)  # what the counters were collected on
         if default_shape and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(dominant)
@@ -268,11 +269,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": "int%d" % (8 * args.bps),
             "data": "synthetic",
             "config": {
-                "workload": "%s nb=%d, %d blocks/GPU/step of %dch x %d x int32 (BASELINE configs[2] shape, xdelta_hzr path), device-resident"
-                % (args.packer, args.nb, B, nch, ns),
+                "workload": "%s nb=%d, %d blocks/GPU/step of %dch x %d x int%d (BASELINE configs[2] shape, xdelta_hzr path), device-resident"
+                % (args.packer, args.nb, B, nch, ns, 8 * args.bps),
                 "blocks_per_gpu": B,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
                 "gather": ("every step" if args.gather_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
