@@ -386,34 +386,68 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
 // control-flow join, so the compiler has no reason to copy a register whose load is in flight
 // (tools/check_stream_regs.py checks the generated code for exactly that).  A stream that has run out of tiles keeps
 // loading item 0 of block 0; lanes past a tile's item count load its last item and skip the transform.
-__device__ __forceinline__ uint32_t stream_load_dword(const uint8_t* base, uint32_t off) {
+// One sample per load for every width: int32 -> dword; int24 -> an UNALIGNED dword at the sample's first byte (the hardware
+// takes it; the byte behind the sample comes along and is shifted out after the wait), int16 -> a sign-extending short.
+template <int BPS>
+__device__ __forceinline__ uint32_t stream_load(const uint8_t* base, uint32_t off) {
     uint32_t v;
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
+    if (BPS == 2)
+        asm volatile("global_load_sshort %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
+    else
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
     return v;
 }
 // RAGGED (ns not a multiple of 16): the last group of a block's last tile is short; its missing rows re-read the last
 // valid one (the transform masks them), so that no load leaves the block.  `tn` = samples in the tile.
-template <bool XDELTA, bool RAGGED>
-__device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t tn, uint32_t q,
+// int24: `lim4` = (bytes from `blk` to the end of the batch) - 4: the dword of the batch's very last sample would end one
+// byte past the buffer, so it starts one byte early instead (stream_fix24 knows).
+template <int BPS, bool XDELTA, bool RAGGED>
+__device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t tn, uint32_t lim4, uint32_t q,
                                                  ItemRegs& R) {
-    const uint32_t rstride = g.nch * 4u;
+    const uint32_t rstride = g.nch * (uint32_t)BPS;
     const uint32_t grp = fast_div(q, g.nch, m_nch);
     const uint32_t c = q - grp * g.nch;
     const uint32_t t = s0 + (grp << 4);
-    const uint32_t off = (t * g.nch + c) * 4u;  // (block_bytes < 4 GiB: the host checks)
+    const uint32_t off = (t * g.nch + c) * (uint32_t)BPS;  // (block_bytes < 4 GiB: the host checks)
     const uint32_t last = RAGGED ? (min(16u, tn - (grp << 4)) - 1u) * rstride : 0u;
 #pragma unroll
-    for (uint32_t e = 0; e < 16; ++e) R.pv[e] = stream_load_dword(blk, off + (RAGGED ? min(e * rstride, last) : e * rstride));
+    for (uint32_t e = 0; e < 16; ++e) {
+        uint32_t o = off + (RAGGED ? min(e * rstride, last) : e * rstride);
+        if (BPS == 3) o = min(o, lim4);
+        R.pv[e] = stream_load<BPS>(blk, o);
+    }
     if (XDELTA) {
         // channel start: the flat array continues from the end of channel c-1 (flat index 0: patched by the consumer)
         const uint32_t cm = c ? c - 1 : 0u;
-        const uint32_t o1 = t ? off - rstride : ((g.ns - 1) * g.nch + cm) * 4u;
-        const uint32_t o2 = t ? off - 2 * rstride : ((g.ns - 2) * g.nch + cm) * 4u;
-        R.p1 = stream_load_dword(blk, o1);
-        R.p2 = stream_load_dword(blk, o2);
+        const uint32_t o1 = t ? off - rstride : ((g.ns - 1) * g.nch + cm) * (uint32_t)BPS;
+        const uint32_t o2 = t ? off - 2 * rstride : ((g.ns - 2) * g.nch + cm) * (uint32_t)BPS;
+        R.p1 = stream_load<BPS>(blk, o1);  // (never the batch's last sample)
+        R.p2 = stream_load<BPS>(blk, o2);
     } else {
         R.p1 = R.p2 = 0;
     }
+}
+// int24: the loaded dwords -> sign-extended samples.  `tail_tile`: the tile that holds the batch's last sample.
+template <bool RAGGED>
+__device__ __forceinline__ void stream_fix24(ItemRegs& R, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t tn, uint32_t lim4, bool tail_tile, uint32_t q) {
+    if (!tail_tile) {
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (uint32_t)((int32_t)(R.pv[e] << 8) >> 8);
+    } else {
+        const uint32_t rstride = g.nch * 3u;
+        const uint32_t grp = fast_div(q, g.nch, m_nch);
+        const uint32_t c = q - grp * g.nch;
+        const uint32_t off = ((s0 + (grp << 4)) * g.nch + c) * 3u;
+        const uint32_t last = RAGGED ? (min(16u, tn - (grp << 4)) - 1u) * rstride : 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            const uint32_t o = off + (RAGGED ? min(e * rstride, last) : e * rstride);
+            // (loaded one byte early: the sample is the top three bytes)
+            R.pv[e] = o > lim4 ? (uint32_t)((int32_t)R.pv[e] >> 8) : (uint32_t)((int32_t)(R.pv[e] << 8) >> 8);
+        }
+    }
+    R.p1 = (uint32_t)((int32_t)(R.p1 << 8) >> 8);
+    R.p2 = (uint32_t)((int32_t)(R.p2 << 8) >> 8);
 }
 // the set's registers pass through the wait, so nothing that reads them can be scheduled above it
 template <int N>
@@ -427,7 +461,7 @@ __device__ __forceinline__ void item_wait(ItemRegs& R) {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool XDELTA, bool RAGGED>
+template <int BPS, bool XDELTA, bool RAGGED>
 __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__ src, Geom g, uint32_t T, uint32_t kfirst, uint32_t kcount,
                                                     uint8_t* __restrict__ planes, uint32_t* __restrict__ needmask,
                                                     uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, uint32_t ablate,
@@ -449,7 +483,11 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     auto tile_items = [&](uint32_t s0_) { return g.nch * ((min(T, g.ns - s0_) + 15u) >> 4); };
 
     // ---- load side of the stream: tile lw, ordinal lj of its l_ipt ----
-    uint32_t lw = skip_untouched(blockIdx.x), lj = 0, l_s0 = 0, l_tn = 16, l_nitems = 1, l_ipt = 0xFFFFFFFFu;
+    uint32_t lw = skip_untouched(blockIdx.x), lj = 0, l_s0 = 0, l_tn = 16, l_nitems = 1, l_ipt = 0xFFFFFFFFu, l_lim4 = 0;
+    auto lim4_of = [&](uint32_t bb) {  // int24: last byte offset (from block bb) at which a dword load stays inside the batch
+        const unsigned long long rest = (unsigned long long)(nblocks - bb) * g.block_bytes - 4ull;
+        return (uint32_t)(rest > 0xFFFFFFFFull ? 0xFFFFFFFFull : rest);
+    };
     const uint8_t* l_blk = src;
     auto l_open = [&]() {
         if (lw < total) {
@@ -458,16 +496,18 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             l_nitems = tile_items(l_s0);
             l_ipt = (l_nitems + nthr - 1) / nthr;
             l_blk = src + (size_t)(lw / tiles_per_block) * g.block_bytes;
+            l_lim4 = lim4_of(lw / tiles_per_block);
         } else {  // out of tiles: keep the ring turning on item 0 of block 0
             l_s0 = 0;
             l_tn = 16;
             l_nitems = 1;
             l_ipt = 0xFFFFFFFFu;
             l_blk = src;
+            l_lim4 = lim4_of(0);
         }
     };
     auto fetch = [&](ItemRegs& R) __attribute__((always_inline)) {
-        load_item_stream<XDELTA, RAGGED>(l_blk, g, m_nch, l_s0, l_tn, min(tid + lj * nthr, l_nitems - 1), R);
+        load_item_stream<BPS, XDELTA, RAGGED>(l_blk, g, m_nch, l_s0, l_tn, l_lim4, min(tid + lj * nthr, l_nitems - 1), R);
         if (++lj == l_ipt) {
             lw = skip_untouched(lw + gridDim.x);
             lj = 0;
@@ -572,7 +612,10 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     auto turn = [&](ItemRegs& R) __attribute__((always_inline)) -> bool {
         item_wait<kAhead>(R);
         const uint32_t q = tid + tj * nthr;
-        if (q < t_nitems) transform_item<4, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
+        if (q < t_nitems) {
+            if (BPS == 3) stream_fix24<RAGGED>(R, g, m_nch, tc.s0, tc.Tn, lim4_of(tc.b), tc.b + 1 == nblocks && tc.s0 + tc.Tn == g.ns, q);
+            transform_item<BPS, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
+        }
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
         if (++tj == t_ipt) {
             const uint32_t tw_next = skip_untouched(tw + gridDim.x);
@@ -836,10 +879,18 @@ INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
-template __global__ void k_tile_stream<true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
-template __global__ void k_tile_stream<true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
-template __global__ void k_tile_stream<false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
-template __global__ void k_tile_stream<false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<2, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<3, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<4, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<2, true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<3, true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<4, true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<2, false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<3, false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<4, false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<2, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<3, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<4, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
 

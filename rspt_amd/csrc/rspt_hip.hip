@@ -208,19 +208,20 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     uint32_t want = per_cu * (uint32_t)p->num_cu;
     if (p->k1_grid) want = p->k1_grid;
     dim3 grid(want < ntiles ? want : ntiles);
-    // aligned int32 input streams (k_tile_stream); anything else takes the general kernel
-    const bool stream = BPS == 4 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && g.ns >= 16 && g.block_bytes < (1ull << 32) &&
+    // int32 / int24 / int16 input streams (k_tile_stream, one load per sample); int8 takes the general kernel
+    const bool stream = BPS >= 2 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && g.ns >= 16 && g.block_bytes < (1ull << 32) &&
                         !(p->ablate & (1u << 22));
     if (stream) {
+        constexpr int SB = BPS >= 2 ? BPS : 4;  // (never instantiated for int8)
         auto go = [&](auto kern) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate,
                                (uint32_t)nblocks, nbuse ? nullptr : p->work_ctr + 1, p->nb_state, p->nbuse, p->plane_dirty, p->dirty_shift);
         };
         if (g.ns & 15u)
-            go(&k_tile_stream<XD, true>);  // (a short last group per channel, plane rows at any byte alignment)
+            go(&k_tile_stream<SB, XD, true>);  // (a short last group per channel, plane rows at any byte alignment)
         else
-            go(&k_tile_stream<XD, false>);
+            go(&k_tile_stream<SB, XD, false>);
         return;
     }
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_planes<BPS, XD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

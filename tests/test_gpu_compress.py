@@ -240,7 +240,8 @@ def test_plane_workspace_carries_nothing_between_calls(api, orc, ns):
 
 
 def test_front_end_shape_fuzz(api, orc):
-    """Random int32 geometries through the streaming front end (k_tile_stream): channel counts on both sides of the wave
+    """Random int32 / int24 / int16 geometries through the streaming front end (k_tile_stream; the int24 loads are
+    unaligned dwords, the batch's very last sample is read one byte early): channel counts on both sides of the wave
     width, ns with and without whole 16-sample groups, tiles with fewer items than threads, several tiles per block,
     batches that escalate nb in the middle (fix-up pass) -- every stream against the oracle, batch after batch on the
     same handle (the plane workspace persists)."""
@@ -250,14 +251,15 @@ def test_front_end_shape_fuzz(api, orc):
     shapes = [(1, 16), (1, 17), (2, 31), (3, 4097), (7, 1000), (12, 8192), (12, 3419), (31, 260), (64, 513), (65, 400), (100, 129), (130, 48),
               (5, 70001), (64, 2048), (20, 16384)]
     for kind in ("xdelta_hzr", "hzr"):
-        for nch, ns in shapes:
+        for si, (nch, ns) in enumerate(shapes):
+            bps = (4, 3, 2)[si % 3] if kind == "xdelta_hzr" else (3, 4, 2)[si % 3]  # int32 / int24 / int16 all stream
             nb0 = int(r.integers(1, 4)) if kind == "xdelta_hzr" else int(r.integers(1, 5))
-            po = orc.packer(kind, 4, nch, ns, nb0)
-            pk = api.SignalPacker(kind, 4, nch, ns, nb0)
+            po = orc.packer(kind, bps, nch, ns, nb0)
+            pk = api.SignalPacker(kind, bps, nch, ns, nb0)
             for call in range(2):
                 B = int(r.integers(1, 5))
                 amps = [int(r.choice([3, 60, 1 << 10, 1 << 14, 1 << 21, 1 << 29])) for _ in range(B)]
-                blocks = [cases._rand_native(nch, ns, 4, int(r.integers(1 << 30)), a, walk=bool(r.integers(2))) for a in amps]
+                blocks = [cases._rand_native(nch, ns, bps, int(r.integers(1 << 30)), a, walk=bool(r.integers(2))) for a in amps]
                 d_src = torch.from_numpy(np.stack(blocks)).cuda()
                 d_dst, d_sizes = pk.compress_batch(d_src)
                 torch.cuda.synchronize()
@@ -266,7 +268,28 @@ def test_front_end_shape_fuzz(api, orc):
                 for i, blk in enumerate(blocks):
                     want = po.compress(blk)
                     got = out[i, : sizes[i]].tobytes()
-                    assert got == want, "%s %dx%d call %d block %d amp %d: %s" % (kind, nch, ns, call, i, amps[i], describe_mismatch(got, want))
+                    assert got == want, "%s int%d %dx%d call %d block %d amp %d: %s" % (kind, 8 * bps, nch, ns, call, i, amps[i], describe_mismatch(got, want))
                 if kind == "xdelta_hzr":
                     assert pk.nb == orc.packer_nb(po)
             pk.close()
+
+
+@pytest.mark.parametrize("bps", [3, 2])
+def test_narrow_samples_full_size_batch(api, orc, bps):
+    """int24 and int16 at the BASELINE shape (64 x 65536), batched: streams equal the oracle's, block by block."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns, B = 64, 65536, 2
+    pk = api.new_xdelta_hzr(bps, nch, ns, 3)
+    d_src = synth.synth_batch_native(B, nch, ns, first_block=3, bps=bps, device="cuda")
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 3)
+    for b in range(B):
+        want = po.compress(d_src[b].cpu().numpy())
+        got = d_dst[b, : int(d_sizes[b])].cpu().numpy().tobytes()
+        assert got == want, describe_mismatch(got, want)
+    assert pk.nb == orc.packer_nb(po)
+    pk.close()

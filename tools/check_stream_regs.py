@@ -51,7 +51,7 @@ def check(lines, name):
             continue
         code = t.split(";")[0].strip()
         if in_asm:
-            m = re.match(r"global_load_dword v(\d+),", code)
+            m = re.match(r"global_load_(?:dword|sshort) v(\d+),", code)
             if m:
                 pending.append(int(m.group(1)))
                 nload += 1
