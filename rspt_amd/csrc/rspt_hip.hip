@@ -148,6 +148,8 @@ struct rspt_hip_packer {
     // dct beyond the dense table: fp64 FFT path (transforms.hip: k_dctfft_*)
     bool dct_fft = false;
     uint32_t fft_l1 = 0, fft_l2 = 0;   // n = 2^(l1+l2)
+    bool dct_real = false;             // forward transform through the real-input FFT (n >= 256)
+    uint32_t fftr_la = 0, fftr_lb = 0; // n/2 = 2^(la+lb)
     double2* fft_tw = nullptr;         // [n] (cos, sin)(2 pi t / n)
     double2* fft_post = nullptr;       // [n] (cos, sin)(pi k / 2n)
     double2* fft_scratch = nullptr;    // [fft_bpp][nch][n]
@@ -269,6 +271,23 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_cols<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctfft_rows<FORWARD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
     const uint32_t fthr = 1024;  // 4096 points per workgroup: 256 threads (4 waves) left the LDS passes latency-bound (34 -> 46 GS/s)
+    if (FORWARD && p->dct_real) {
+        // real-input form (k_dctr_*): M = n/2 complex points, half the scratch round trip
+        const uint32_t la = p->fftr_la, lb = p->fftr_lb;
+        const uint32_t lwr = std::min(kFftLdsLog - la, lb);
+        const uint32_t ldsc = ((uint32_t)sizeof(double2) << (la + lwr)) + ((uint32_t)sizeof(double2) << (la - 1));
+        const uint32_t ldsr = ((uint32_t)sizeof(double2) << kFftLdsLog) + ((uint32_t)sizeof(double2) << (lb - 1));
+        const uint32_t R = 1u << (kFftLdsLog - lb - 1), npairs = (1u << (la - 1)) - 1, ngroups = (npairs + R - 1) / R;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctr_cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dctr_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+        for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
+            const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
+            hipLaunchKernelGGL(k_dctr_cols, dim3(1u << (lb - lwr), g.nch, nbk), dim3(fthr), ldsc, st, in, g, p->mean_i32, p->fft_tw, p->fft_scratch, la, lb, b0);
+            hipLaunchKernelGGL(k_dctr_rows, dim3(ngroups + 1, g.nch, nbk), dim3(fthr), ldsr, st, p->fft_scratch, g, p->fft_tw, p->fft_post, out, la, lb, b0,
+                               p->dct_scale0, p->dct_scale1);
+        }
+        return;
+    }
     for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
         const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
         hipLaunchKernelGGL((k_dctfft_cols<FORWARD>), dim3(1u << (l2 - lw), g.nch, nbk), dim3(fthr), lds_c, st, in, g, p->mean_i32, p->fft_tw,
@@ -449,6 +468,13 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
             while ((1ull << k) < ns) ++k;
             p->fft_l1 = (k + 1) / 2;
             p->fft_l2 = k / 2;
+            const char* noreal = getenv("RSPT_DCT_REAL");
+            if (k >= 8 && !(noreal && atoi(noreal) == 0)) {  // n/2 = m1*m2 with m2 = 64 where it can be (whole-line output runs)
+                const uint32_t lM = k - 1;
+                p->fftr_lb = lM > 18 ? lM - 12 : 6;
+                p->fftr_la = lM - p->fftr_lb;
+                p->dct_real = true;
+            }
         }
     }
     hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);

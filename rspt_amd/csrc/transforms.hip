@@ -563,6 +563,126 @@ __global__ __launch_bounds__(1024) void k_dctfft_rows(const double2* __restrict_
     }
 }
 
+// ---- forward DCT through a REAL-input FFT: half the points, half the scratch round trip ----------------------------------
+// v (Makhoul's permutation of the n real samples) is packed as z[m] = v[2m] + i v[2m+1], M = n/2 complex points;
+// Z = FFT_M(z) by the same four-step scheme (M = m1*m2, m = j1*m2 + j2, k = k1 + m1*k2), and
+//   E[k] = (Z[k] + conj Z[M-k]) / 2,  O[k] = (Z[k] - conj Z[M-k]) / 2i,  w = e^{-2 pi i k / n}
+//   V[k] = E + w O,  V[k+M] = E - w O,  V[M-k] = conj V[k+M],  V[n-k] = conj V[k]           (0 < k < M, k != M/2)
+//   V[0] = Re Z0 + Im Z0,  V[M] = Re Z0 - Im Z0;  k = M/2 pairs with itself
+// so a (k, M-k) pair of Z gives four DCT coefficients C[x] = Re(e^{-i pi x / 2n} V[x]).  Z[M-k] sits in row m1-k1 (column
+// m2-1-k2) of the second FFT stage: a workgroup of k_dctr_rows therefore takes R rows p..p+R-1 together with their
+// mirrors m1-p-R+1..m1-p; rows 0 and m1/2 pair within themselves and go to one extra workgroup.  m2 = 64 where it can
+// be, so that R = 32 and every run of output coefficients is a whole 128-byte line.
+__device__ __forceinline__ double dctr_sample(const int32_t* __restrict__ row, uint32_t n, int32_t mean, uint32_t j) {
+    // v[j] = s[2j] (j < n/2), v[n-1-j] = s[2j+1]; s = (float)(src - mean) as in dct.cpp:80,108-109
+    const uint32_t x = j < (n >> 1) ? 2u * j : 2u * (n - 1u - j) + 1u;
+    return (double)(float)(int32_t)((uint32_t)row[x] - (uint32_t)mean);
+}
+
+__global__ __launch_bounds__(1024) void k_dctr_cols(const int32_t* __restrict__ in, Geom g, const int32_t* __restrict__ mean_i32,
+                                                   const double2* __restrict__ tw, double2* __restrict__ scratch, uint32_t la, uint32_t lb,
+                                                   uint32_t b0) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = la + lb + 1, M = n >> 1;
+    const uint32_t lw = min(kFftLdsLog - la, lb), W = 1u << lw;
+    const uint32_t j2_0 = blockIdx.x << lw, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const int32_t* row = in + (size_t)b * g.N + (size_t)c * n;
+    const uint32_t total = 1u << (la + lw);
+    double2* stw = shf + total;
+    load_stage_twiddles(stw, tw, la, nlog);
+    const int32_t mean = mean_i32[(size_t)b * g.nch + c];
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), j1 = idx >> lw;
+        const uint32_t m = (j1 << lb) + j2_0 + col;
+        shf[bitrev(j1, la) * W + col] = make_double2(dctr_sample(row, n, mean, 2u * m), dctr_sample(row, n, mean, 2u * m + 1u));
+    }
+    __syncthreads();
+    lds_fft(shf, stw, la, lw, false);
+    double2* dst = scratch + ((size_t)bl * g.nch + c) * M;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), k1 = idx >> lw;
+        const uint32_t j2 = j2_0 + col;
+        const double2 w = tw[2u * j2 * k1];  // e^{2 pi i j2 k1 / M}; j2*k1 < M
+        const double2 z = shf[k1 * W + col];
+        dst[((size_t)k1 << lb) + j2] = make_double2(z.x * w.x + z.y * w.y, z.y * w.x - z.x * w.y);  // z * conj(w)
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_dctr_rows(const double2* __restrict__ scratch, Geom g, const double2* __restrict__ tw,
+                                                   const double2* __restrict__ post, int32_t* __restrict__ out, uint32_t la, uint32_t lb,
+                                                   uint32_t b0, double scale0, double scale1) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = la + lb + 1, M = n >> 1, m1 = 1u << la, m2 = 1u << lb;
+    const uint32_t lr = kFftLdsLog - lb, RR = 1u << lr, R = RR >> 1;  // RR sequences in LDS: R rows and their R mirrors
+    const uint32_t npairs = (m1 >> 1) - 1;                            // rows 1 .. m1/2-1 pair with m1-1 .. m1/2+1
+    const uint32_t ngroups = (npairs + R - 1) / R;
+    const uint32_t grp = blockIdx.x, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const bool special = grp == ngroups;  // rows 0 and m1/2
+    const uint32_t p0 = 1u + grp * R;
+    const uint32_t total = RR << lb;
+    double2* stw = shf + total;
+    load_stage_twiddles(stw, tw, lb, nlog);
+    const double2* src = scratch + ((size_t)bl * g.nch + c) * M;
+    // sequence q of the workgroup: q < R: row p0 + q; q >= R: row m1 - (p0 + q - R)   (special: q = 0: row 0, q = 1: row m1/2)
+    auto row_of = [&](uint32_t q) -> uint32_t {
+        if (special) return q == 0 ? 0u : q == 1 ? (m1 >> 1) : 0xFFFFFFFFu;
+        const uint32_t p = p0 + (q & (R - 1));
+        if (p > npairs) return 0xFFFFFFFFu;
+        return q < R ? p : m1 - p;
+    };
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t q = idx >> lb, j2 = idx & (m2 - 1);
+        const uint32_t r = row_of(q);
+        shf[bitrev(j2, lb) * RR + q] = r != 0xFFFFFFFFu ? src[((size_t)r << lb) + j2] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    lds_fft(shf, stw, lb, lr, false);
+    int32_t* orow = out + (size_t)b * g.N + (size_t)c * n;
+    // C[x] = trunc(Re(e^{-i pi x / 2n} V) * Cs[x]*sqrt(2/n)/128)   (dct.cpp:84-85)
+    auto emit = [&](uint32_t x, double vr, double vi) {
+        const double2 pw = post[x];
+        orow[x] = (int32_t)((pw.x * vr + pw.y * vi) * (x == 0 ? scale0 : scale1));
+    };
+    auto pair_out = [&](uint32_t k, const double2& za, const double2& zb) {  // za = Z[k], zb = Z[M-k]; 0 < k < M, k != M/2
+        const double er = 0.5 * (za.x + zb.x), ei = 0.5 * (za.y - zb.y);     // E
+        const double orr = 0.5 * (za.y + zb.y), oi = -0.5 * (za.x - zb.x);   // O = (za - conj zb) / 2i
+        const double2 w = tw[k];                                             // e^{+2 pi i k/n}: multiply by its conjugate
+        const double tr = orr * w.x + oi * w.y, ti = oi * w.x - orr * w.y;   // w' O
+        emit(k, er + tr, ei + ti);              // V[k]
+        emit(k + M, er - tr, ei - ti);          // V[k+M]
+        emit(M - k, er - tr, -(ei - ti));       // V[M-k] = conj V[k+M]
+        emit(n - k, er + tr, -(ei + ti));       // V[n-k] = conj V[k]
+    };
+    if (!special) {
+        for (uint32_t idx = threadIdx.x; idx < (R << lb); idx += blockDim.x) {
+            const uint32_t r = idx & (R - 1), k2 = idx >> (lr - 1);
+            const uint32_t p = p0 + r;
+            if (p > npairs) continue;
+            pair_out(p + (k2 << la), shf[k2 * RR + r], shf[(m2 - 1 - k2) * RR + R + r]);
+        }
+    } else {
+        // row 0: k = m1 k2 pairs with column m2 - k2; k2 = 0 and k2 = m2/2 pair with themselves
+        for (uint32_t k2 = threadIdx.x; k2 <= (m2 >> 1); k2 += blockDim.x) {
+            const double2 za = shf[k2 * RR];
+            if (k2 == 0) {
+                emit(0, za.x + za.y, 0.0);  // V[0] = Re Z0 + Im Z0
+                emit(M, za.x - za.y, 0.0);  // V[M] = Re Z0 - Im Z0
+            } else if (k2 == (m2 >> 1)) {
+                // k = M/2: E = Re Z, O = Im Z, w = e^{-i pi/2}: V[M/2] = conj Z, V[3M/2] = Z
+                emit(M >> 1, za.x, -za.y);
+                emit(M + (M >> 1), za.x, za.y);
+            } else {
+                pair_out(k2 << la, za, shf[(m2 - k2) * RR]);
+            }
+        }
+        // row m1/2: k = m1/2 + m1 k2 pairs with column m2 - 1 - k2 of the same row (never with itself)
+        if (m1 >= 2) {
+            for (uint32_t k2 = threadIdx.x; k2 < (m2 >> 1); k2 += blockDim.x)
+                pair_out((m1 >> 1) + (k2 << la), shf[k2 * RR + 1], shf[(m2 - 1 - k2) * RR + 1]);
+        }
+    }
+}
+
 template __global__ void k_dctfft_cols<true>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
                                              uint32_t, float);
 template __global__ void k_dctfft_cols<false>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
