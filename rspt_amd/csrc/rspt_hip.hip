@@ -288,6 +288,23 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
         }
         return;
     }
+    if (!FORWARD && p->dct_real) {
+        // real-output form (k_idctr_*)
+        const uint32_t la = p->fftr_la, lb = p->fftr_lb;
+        const uint32_t lwr = std::min(kFftLdsLog - la, lb), lrr = std::min(kFftLdsLog - lb, la);
+        const uint32_t ldsc = ((uint32_t)sizeof(double2) << (la + lwr)) + ((uint32_t)sizeof(double2) << (la - 1));
+        const uint32_t ldsr = ((uint32_t)sizeof(double2) << (lb + lrr)) + ((uint32_t)sizeof(double2) << (lb - 1));
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idctr_cols), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_idctr_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr);
+        for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
+            const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
+            hipLaunchKernelGGL(k_idctr_cols, dim3(1u << (lb - lwr), g.nch, nbk), dim3(fthr), ldsc, st, in, g, p->fft_tw, p->fft_post, p->fft_scratch, la, lb, b0,
+                               p->dct_cs0);
+            hipLaunchKernelGGL(k_idctr_rows, dim3(1u << (la - lrr), g.nch, nbk), dim3(fthr), ldsr, st, p->fft_scratch, g, p->means, p->fft_tw, out, la, lb, b0,
+                               p->idct_scale);
+        }
+        return;
+    }
     for (uint32_t b0 = 0; b0 < B; b0 += (uint32_t)p->fft_bpp) {
         const uint32_t nbk = std::min<uint32_t>((uint32_t)p->fft_bpp, B - b0);
         hipLaunchKernelGGL((k_dctfft_cols<FORWARD>), dim3(1u << (l2 - lw), g.nch, nbk), dim3(fthr), lds_c, st, in, g, p->mean_i32, p->fft_tw,

@@ -683,6 +683,87 @@ __global__ __launch_bounds__(1024) void k_dctr_rows(const double2* __restrict__ 
     }
 }
 
+// ---- inverse DCT through a real-OUTPUT FFT ---------------------------------------------------------------------------------
+// With V'[k] = e^{+i pi k/2n} (Y'[k] - i Y'[n-k]) (Hermitian: the n-point inverse transform v is real),
+//   Z'[k] = (V'[k] + V'[k+M]) + i e^{+2 pi i k/n} (V'[k] - V'[k+M]),  k < M = n/2
+// and the M-point inverse transform of Z' is z[m] = v[2m] + i v[2m+1]: half the points and half the scratch again.  The
+// pairing is on the input side here (every Z' needs four coefficients), the rows come out unpaired.
+__global__ __launch_bounds__(1024) void k_idctr_cols(const int32_t* __restrict__ in, Geom g, const double2* __restrict__ tw,
+                                                    const double2* __restrict__ post, double2* __restrict__ scratch, uint32_t la, uint32_t lb,
+                                                    uint32_t b0, float cs0) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = la + lb + 1, M = n >> 1;
+    const uint32_t lw = min(kFftLdsLog - la, lb), W = 1u << lw;
+    const uint32_t j2_0 = blockIdx.x << lw, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const int32_t* row = in + (size_t)b * g.N + (size_t)c * n;
+    const uint32_t total = 1u << (la + lw);
+    double2* stw = shf + total;
+    load_stage_twiddles(stw, tw, la, nlog);
+    auto vprime = [&](uint32_t x) -> double2 {  // V'[x], x < n  (dct.cpp:95: Cs[0]*dct[0] in float)
+        double yk, ynk;
+        if (x == 0) {
+            yk = (double)__fmul_rn(cs0, (float)row[0]);
+            ynk = 0.0;
+        } else {
+            yk = 0.5 * (double)(float)row[x];
+            ynk = 0.5 * (double)(float)row[n - x];
+        }
+        const double2 pw = post[x];
+        return make_double2(pw.x * yk + pw.y * ynk, pw.y * yk - pw.x * ynk);
+    };
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), j1 = idx >> lw;
+        const uint32_t k = (j1 << lb) + j2_0 + col;
+        const double2 a = vprime(k), bq = vprime(k + M);
+        const double2 w = tw[k];
+        const double dx = a.x - bq.x, dy = a.y - bq.y;
+        // (a + b) + i w (a - b)
+        shf[bitrev(j1, la) * W + col] = make_double2(a.x + bq.x - (w.x * dy + w.y * dx), a.y + bq.y + (w.x * dx - w.y * dy));
+    }
+    __syncthreads();
+    lds_fft(shf, stw, la, lw, true);
+    double2* dst = scratch + ((size_t)bl * g.nch + c) * M;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t col = idx & (W - 1), k1 = idx >> lw;
+        const uint32_t j2 = j2_0 + col;
+        const double2 w = tw[2u * j2 * k1];  // e^{+2 pi i j2 k1 / M}
+        const double2 z = shf[k1 * W + col];
+        dst[((size_t)k1 << lb) + j2] = make_double2(z.x * w.x - z.y * w.y, z.x * w.y + z.y * w.x);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_idctr_rows(const double2* __restrict__ scratch, Geom g, const uint8_t* __restrict__ means,
+                                                    const double2* __restrict__ tw, int32_t* __restrict__ out, uint32_t la, uint32_t lb,
+                                                    uint32_t b0, double scale1) {
+    extern __shared__ __attribute__((aligned(16))) double2 shf[];
+    const uint32_t n = g.ns, nlog = la + lb + 1, M = n >> 1, m2 = 1u << lb;
+    const uint32_t lr = min(kFftLdsLog - lb, la), R = 1u << lr;
+    const uint32_t k1_0 = blockIdx.x << lr, c = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    const uint32_t total = R << lb;
+    double2* stw = shf + total;
+    load_stage_twiddles(stw, tw, lb, nlog);
+    const double2* src = scratch + ((size_t)bl * g.nch + c) * M + ((size_t)k1_0 << lb);
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t r = idx >> lb, j2 = idx & (m2 - 1);
+        shf[bitrev(j2, lb) * R + r] = src[idx];
+    }
+    __syncthreads();
+    lds_fft(shf, stw, lb, lr, true);
+    int32_t* orow = out + (size_t)b * g.N + (size_t)c * n;
+    const int32_t mean = load_mean_hdr(means, g, b, c);
+    auto put = [&](uint32_t j, double v) {  // v[j] -> its sample: s[2j] = v[j] (j < n/2), s[2j+1] = v[n-1-j]
+        const uint32_t i = j < (n >> 1) ? 2u * j : 2u * (n - 1u - j) + 1u;
+        orow[i] = (int32_t)((uint32_t)(int32_t)(v * scale1) + (uint32_t)mean);  // sqrt(2/n)*128, C truncation (dct.cpp:97-98)
+    };
+    for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        const uint32_t r = idx & (R - 1), k2 = idx >> lr;
+        const uint32_t m = k1_0 + r + (k2 << la);
+        const double2 z = shf[k2 * R + r];
+        put(2u * m, z.x);
+        put(2u * m + 1u, z.y);
+    }
+}
+
 template __global__ void k_dctfft_cols<true>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
                                              uint32_t, float);
 template __global__ void k_dctfft_cols<false>(const int32_t*, Geom, const int32_t*, const double2*, const double2*, double2*, uint32_t, uint32_t,
