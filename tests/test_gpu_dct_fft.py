@@ -54,7 +54,7 @@ def _coeff_mismatch(orc, a, b, bps, nch, ns):
     return float((d != 0).mean()), int(d.max())
 
 
-@pytest.mark.parametrize("nch,ns", [(3, 16), (2, 64), (5, 1024), (4, 4096), (2, 8192)])
+@pytest.mark.parametrize("nch,ns", [(3, 16), (2, 64), (3, 256), (2, 512), (5, 1024), (2, 2048), (4, 4096), (2, 8192)])
 def test_forced_fft_path_vs_reference_arithmetic(api, orc, nch, ns, monkeypatch):
     data = _block(nch, ns, 3)
     want = orc.packer("dct", 4, nch, ns).compress(data)  # the reference's arithmetic (pinned in test_oracle_vs_ref)
