@@ -81,7 +81,7 @@ def test_forced_fft_path_vs_reference_arithmetic(api, orc, nch, ns, monkeypatch)
     pk.close()
 
 
-@pytest.mark.parametrize("bps,nch,ns,nblocks", [(4, 3, 16384, 2), (3, 2, 32768, 1), (4, 64, 65536, 1), (4, 2, 262144, 1)])
+@pytest.mark.parametrize("bps,nch,ns,nblocks", [(4, 3, 16384, 2), (3, 2, 32768, 1), (4, 64, 65536, 1), (4, 2, 262144, 1), (4, 1, 1048576, 1), (4, 1, 4194304, 1)])
 def test_dct_large_ns(api, orc, bps, nch, ns, nblocks):
     import torch
 
