@@ -419,9 +419,15 @@ __device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom&
     if (XDELTA) {
         // channel start: the flat array continues from the end of channel c-1 (flat index 0: patched by the consumer)
         const uint32_t cm = c ? c - 1 : 0u;
-        const uint32_t o1 = t ? off - rstride : ((g.ns - 1) * g.nch + cm) * (uint32_t)BPS;
-        const uint32_t o2 = t ? off - 2 * rstride : ((g.ns - 2) * g.nch + cm) * (uint32_t)BPS;
-        R.p1 = stream_load<BPS>(blk, o1);  // (never the batch's last sample)
+        uint32_t o1 = t ? off - rstride : ((g.ns - 1) * g.nch + cm) * (uint32_t)BPS;
+        uint32_t o2 = t ? off - 2 * rstride : ((g.ns - 2) * g.nch + cm) * (uint32_t)BPS;
+        if (BPS == 3) {
+            // with one channel the (discarded) halo of flat index 0 is the block's last sample: its dword, too, must not
+            // leave the batch.  A clamped halo is only ever the discarded one, so stream_fix24 need not know.
+            o1 = min(o1, lim4);
+            o2 = min(o2, lim4);
+        }
+        R.p1 = stream_load<BPS>(blk, o1);
         R.p2 = stream_load<BPS>(blk, o2);
     } else {
         R.p1 = R.p2 = 0;

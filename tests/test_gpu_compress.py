@@ -249,7 +249,7 @@ def test_front_end_shape_fuzz(api, orc):
 
     r = np.random.default_rng(20251)
     shapes = [(1, 16), (1, 17), (2, 31), (3, 4097), (7, 1000), (12, 8192), (12, 3419), (31, 260), (64, 513), (65, 400), (100, 129), (130, 48),
-              (5, 70001), (64, 2048), (20, 16384)]
+              (5, 70001), (64, 2048), (20, 16384), (2, 1000003), (1, 1 << 21)]
     for kind in ("xdelta_hzr", "hzr"):
         for si, (nch, ns) in enumerate(shapes):
             bps = (4, 3, 2)[si % 3] if kind == "xdelta_hzr" else (3, 4, 2)[si % 3]  # int32 / int24 / int16 all stream
@@ -292,4 +292,27 @@ def test_narrow_samples_full_size_batch(api, orc, bps):
         got = d_dst[b, : int(d_sizes[b])].cpu().numpy().tobytes()
         assert got == want, describe_mismatch(got, want)
     assert pk.nb == orc.packer_nb(po)
+    pk.close()
+
+
+@pytest.mark.parametrize("nch", [1, 3])
+def test_int24_batch_that_ends_with_its_allocation(api, orc, nch):
+    """int24 samples are read as unaligned 4-byte words: nothing may be read past the last byte of the batch.  A batch of
+    more than 10 MiB whose size is a multiple of 2 MiB ends exactly where its device allocation ends (an access past it
+    is a GPU memory fault, not a silent over-read); one channel makes the discarded halo of flat index 0 the block's last
+    sample."""
+    import torch
+
+    ns = (1 << 21) if nch == 1 else (1 << 20)  # 6 MiB resp. 9 MiB per block: two blocks are a multiple of 2 MiB
+    pk = api.new_xdelta_hzr(3, nch, ns, 2)
+    blocks = [cases._rand_native(nch, ns, 3, 4100 + i, a, walk=True) for i, a in enumerate([40, 1 << 13])]
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    assert d_src.numel() % (2 << 20) == 0 and d_src.numel() > (10 << 20)
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    po = orc.packer("xdelta_hzr", 3, nch, ns, 2)
+    for i, blk in enumerate(blocks):
+        want = po.compress(blk)
+        got = d_dst[i, : int(d_sizes[i])].cpu().numpy().tobytes()
+        assert got == want, describe_mismatch(got, want)
     pk.close()
