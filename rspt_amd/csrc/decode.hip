@@ -198,27 +198,27 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
             }
             sym = wv & 511u;
         }
-        uint32_t used = len;
-        if (sym < 256) {
-            if (WRITE && o < out_size) {
-                // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
-                // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
-                const uint32_t dw = o >> 2;
-                if (dw != cur_dw) {
-                    if (acc) flush_dword(out, cur_dw, acc);
-                    cur_dw = dw;
-                    acc = 0;
-                }
-                acc |= sym << ((o & 3u) * 8);
+        // literal: one byte.  Run symbols 256..260 (hzr_internal.h:117-121): 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14
+        // extra bits -- looked up in two packed constants, not branched on: with 64 lanes in step some lane holds a run
+        // symbol in a fifth of the iterations even on the dense plane
+        const bool lit = sym < 256;
+        const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
+        const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
+        const uint32_t zbase = ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
+        const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+        if (WRITE && lit && o < out_size) {
+            // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
+            // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
+            const uint32_t dw = o >> 2;
+            if (dw != cur_dw) {
+                if (acc) flush_dword(out, cur_dw, acc);
+                cur_dw = dw;
+                acc = 0;
             }
-            ++o;
-        } else {
-            const uint32_t eb = run_extra_bits(sym);
-            uint32_t z = sym == 256 ? 2u : sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : 279u;
-            z += (uint32_t)(win >> len) & ((1u << eb) - 1u);
-            used += eb;
-            o += z;
+            acc |= sym << ((o & 3u) * 8);
         }
+        o += lit ? 1u : zbase + extra;
+        const uint32_t used = len + eb;
         win >>= used;
         navail -= used;
         bp += used;
