@@ -316,3 +316,28 @@ def test_int24_batch_that_ends_with_its_allocation(api, orc, nch):
         got = d_dst[i, : int(d_sizes[i])].cpu().numpy().tobytes()
         assert got == want, describe_mismatch(got, want)
     pk.close()
+
+
+def test_full_size_dense_then_quiet_on_one_handle(api, orc):
+    """BASELINE shape (64 x 65536 x int32): a batch of wide random samples (nb escalates to 4, every plane dense: all hzr
+    blocks flagged dirty), then quiet synthetic blocks on the same handle (the upper planes turn sparse: the front end
+    must overwrite what the dense batch left), then the dense ones again -- every stream against the oracle."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns = 64, 65536
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    po = orc.packer("xdelta_hzr", 4, nch, ns, 3)
+    dense = [cases._rand_native(nch, ns, 4, 900 + i, 1 << 29) for i in range(2)]
+    quiet = [synth.synth_native(nch, ns, block_index=40 + i).numpy().reshape(-1) for i in range(2)]
+    for blocks in (dense, quiet, dense[:1] + quiet[:1]):
+        d_src = torch.from_numpy(np.stack(blocks)).cuda()
+        d_dst, d_sizes = pk.compress_batch(d_src)
+        torch.cuda.synchronize()
+        for i, blk in enumerate(blocks):
+            want = po.compress(blk)
+            got = d_dst[i, : int(d_sizes[i])].cpu().numpy().tobytes()
+            assert got == want, describe_mismatch(got, want)
+        assert pk.nb == orc.packer_nb(po) == 4
+    pk.close()
