@@ -1,21 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py -- MSamples/s of xdelta_hzr compress on 64ch x 65536 x int32 blocks.
+"""bench.py -- MSamples/s of signal_packer compress on MI355X (default: xdelta_hzr, 64ch x 65536 x int32).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c5] [--packer ...]
 
-One "step" = one pass of the hot path (rspt_hip_compress_batch_dev) over one
-batch of `--blocks` synthetic blocks per GPU, inputs already resident in HBM.
-For N > 1 the driver launches this file under torch.distributed.run, one rank
-per GPU; blocks are independent, so every rank compresses its own shard (weak
-scaling) and the compressed streams are gathered to rank 0 over RCCL.
+One "step" = one pass of the hot path (rspt_hip_compress_batch_dev) over one batch of
+synthetic blocks per GPU, inputs already resident in HBM.  Two distinct batches alternate in
+the timed loop.  With --gpus N > 1 and no RANK in the environment this process only starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (before any GPU
+call) and relays rank 0's JSON line; under torch.distributed.run it is one rank per GPU.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: `roofline` (dominant kernel, HIP-event timed on the launch stream) and
-`cpu_baseline` (the checker library timed on this node's host cores, N=1 only).
+  --workload c3  (default) weak scaling: every rank compresses its own `--blocks` blocks of
+                 nch x ns (BASELINE configs[2] shape on the xdelta_hzr path); the ranks exchange
+                 the sizes index every step (RCCL all-gather), the payload once after the timed steps
+  --workload c5  strong scaling: 1024 blocks of 12ch x 8192 in total (BASELINE configs[4]), contiguous
+                 shards per rank (shard.shard_range), container pack + RCCL gather to rank 0 INSIDE
+                 the timed step
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(HIP-event timed on the launch stream), `cpu_baseline` (the checker library timed on
+this node's host cores, N=1 only) and `verified` (streams of both batches compared with
+the oracle after the timed region).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -24,37 +35,101 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+C5_TOTAL_BLOCKS = 1024
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=64, help="blocks per GPU per step (each 64ch x 65536 x int32 = 16 MiB)")
-    ap.add_argument("--nch", type=int, default=64)
-    ap.add_argument("--ns", type=int, default=65536)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--blocks", type=int, default=None, help="c3: blocks per GPU per step (default 64); c5: total blocks (default 1024)")
+    ap.add_argument("--nch", type=int, default=None)
+    ap.add_argument("--ns", type=int, default=None)
     ap.add_argument("--nb", type=int, default=3)
     ap.add_argument("--bps", type=int, default=4, choices=[1, 2, 3, 4], help="bytes per sample of the input (the metric is quoted on 4)")
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
     ap.add_argument("--gather-every-step", action="store_true",
-                    help="N>1: ship every step's streams to rank 0 (link-bound beyond 2-3 GPUs: see DESIGN.md); default: the sizes "
-                         "index every step, the payload once after the timed steps")
+                    help="c3, N>1: ship every step's streams to rank 0 (link-bound beyond 2-3 GPUs: see DESIGN.md)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the produced streams")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--verify", action="store_true", help="check one block of the batch against the oracle before timing")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.workload == "c5":
+        a.nch = a.nch or 12
+        a.ns = a.ns or 8192
+        a.blocks = a.blocks or C5_TOTAL_BLOCKS
+    else:
+        a.nch = a.nch or 64
+        a.ns = a.ns or 65536
+        a.blocks = a.blocks or 64
+    return a
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks ourselves (a child process, no exec),
+    relay rank 0's JSON line, fail loudly if the node cannot run N ranks."""
+    import torch  # device_count() does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but %d device(s) visible; refusing to report a smaller run\n" % (args.gpus, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + "\n")
+    if p.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit %d)\n" % (args.gpus, p.returncode))
+        return p.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def cpu_info():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                pid = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return model, len(phys) or (os.cpu_count() or 1), os.cpu_count() or 1, usable
 
 
 def cpu_baseline(args, sample_native):
     """Time the checker on host cores: oracle/_ref (the compiled reference) when the
-    prebuilt library travelled here, else our restatement.  Bounded sample."""
+    prebuilt library travelled here, else our restatement.  Bounded sample; one packer
+    instance per thread on every core this process may use."""
     from oracle import oracle as orc_mod
 
     kind = "reference" if orc_mod.have_ref() else "port"
     lib = orc_mod.Ref() if kind == "reference" else orc_mod.Oracle()
-    nthreads = min(os.cpu_count() or 1, 16)
+    model, physical, logical, usable = cpu_info()
+    nthreads = max(1, min(usable, physical))  # every physical core this process may run on
     samples_per_block = args.nch * args.ns
     counts = [0] * nthreads
     deadline = [0.0]
@@ -92,20 +167,40 @@ def cpu_baseline(args, sample_native):
         "cores": nthreads,
         "kind": kind,
         "value_1core": round(n1 * samples_per_block / dt1 / 1e6, 2),
-        "sample": "%d + %d compress() calls of one %dch x %d x int32 synthetic block (%s), verify-decode included as in the reference"
-        % (n1, sum(counts), args.nch, args.ns, args.packer),
+        "cpu_model": model,
+        "cpus": {"physical": physical, "logical": logical, "usable": usable},
+        "sample": "%d + %d compress() calls of one %dch x %d x int%d synthetic block (%s), verify-decode included as in the reference"
+        % (n1, sum(counts), args.nch, args.ns, 8 * args.bps, args.packer),
     }
+
+
+def kernels_sha():
+    """fingerprint of the kernel sources: counters collected on other sources are stale"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rspt_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def main():
     args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
     import torch
 
-    from rspt_amd import api, synth
+    from rspt_amd import api, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
+    api.lib()  # load (never build: a stale library fails loudly) before any GPU call
     dist = None
     if "RANK" in os.environ:  # launched by torch.distributed.run (also with one rank: same code path)
         import torch.distributed as dist
@@ -116,59 +211,65 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    B, nch, ns = args.blocks, args.nch, args.ns
+    nch, ns = args.nch, args.ns
+    c5 = args.workload == "c5"
+    if c5:
+        first, B = shard.shard_range(args.blocks, rank, world)  # this rank's contiguous shard of the job's blocks
+        total_blocks = args.blocks
+    else:
+        B = args.blocks
+        first = rank * B
+        total_blocks = world * B
     pk = api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank)
     pk.reserve(B)
-    # synthetic input, resident in HBM; every rank gets different blocks (SURVEY 8d generator)
-    d_src = synth.synth_batch_native(B, nch, ns, first_block=rank * B, bps=args.bps, device=dev)
+    # synthetic input, resident in HBM: TWO distinct batches alternate in the timed loop (the front end's behaviour depends on
+    # what the previous call left in the plane workspace); every rank gets different blocks (SURVEY 8d generator)
+    d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(2)]
     dst_stride = (pk.max_compressed_size + 255) // 256 * 256
     d_dst = [torch.empty((B, dst_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
     d_sizes = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(2)]
     stream = torch.cuda.current_stream(dev)
 
-    if args.verify and rank == 0:
-        from oracle.oracle import Oracle
-
-        pk.compress_batch(d_src, d_dst[0], d_sizes[0], dst_stride)
-        torch.cuda.synchronize()
-        o = Oracle()
-        po = o.packer(args.packer, 4, nch, ns, args.nb)
-        want = po.compress(d_src[0].cpu().numpy())
-        got = d_dst[0][0, : int(d_sizes[0][0])].cpu().numpy().tobytes()
-        assert got == want, "GPU stream differs from the oracle"
-
     # gather plan (N>1): each rank packs its streams into a container on the device
     # (rspt_hip_pack_batch_dev) and the containers go to rank 0 over RCCL: sizes by
-    # all_gather, payload by send/recv (rspt_amd/shard.py).  It runs on a side stream so
-    # that step i's gather overlaps step i+1's compression.
-    from rspt_amd import shard
-
+    # all_gather, payload by send/recv (rspt_amd/shard.py).
     do_gather = dist is not None and not args.no_gather
-    side = torch.cuda.Stream(dev) if do_gather else None
+    payload_every_step = c5 or args.gather_every_step
+    need_pack = c5 or do_gather
+    side = torch.cuda.Stream(dev) if (do_gather and not c5) else None
     bound = pk.pack_bound(B)
-    packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(2)] if do_gather else None
-    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
+    packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(2)] if need_pack else None
+    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)] if need_pack else None
     recv_bufs = None
     if do_gather and rank == 0:
-        recv_bufs = [None] + [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(world - 1)]
+        recv_bufs = [None] + [torch.empty(pk.pack_bound(shard.shard_range(args.blocks, r, world)[1] if c5 else B), dtype=torch.uint8, device=dev)
+                              for r in range(1, world)]
     gathered_bytes = [0]
     slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
-
-    sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if do_gather else None
+    sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if (do_gather and not c5) else None
 
     def one_step(i):
         slot = i & 1
+        if c5:
+            # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step
+            pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
+            pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
+            if do_gather:
+                got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
+                if got is not None:
+                    gathered_bytes[0] = sum(n for _, n in got)
+            return
         if slot_free[slot] is not None and not slot_free[slot].query():  # (two steps old: almost always done -- then no barrier packet)
             stream.wait_event(slot_free[slot])
-        pk.compress_batch(d_src, d_dst[slot], d_sizes[slot], dst_stride)
+        pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
         if do_gather:
-            if args.gather_every_step:
+            if payload_every_step:
                 pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
             ev = torch.cuda.Event()
             ev.record(stream)
             side.wait_event(ev)
             with torch.cuda.stream(side):
-                if args.gather_every_step:
+                if payload_every_step:
                     got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
                     if got is not None:
                         gathered_bytes[0] = sum(n for _, n in got)
@@ -198,10 +299,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
+    # c3, N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
     # could take the output of only 2-3 GPUs at this rate); its time is reported beside the metric
     gather_ms = None
-    if do_gather and not args.gather_every_step:
+    if do_gather and not payload_every_step:
         last = (args.steps - 1) & 1
         torch.cuda.synchronize()
         dist.barrier()
@@ -214,19 +315,41 @@ def main():
         if got is not None:
             gathered_bytes[0] = sum(n for _, n in got)
 
-    # per-kernel durations (HIP events on the launch stream), separate profiled pass
+    # outside the timed region: both batches once more, their first and last streams against the oracle
+    verified = None
+    for s in range(2):
+        pk.compress_batch(d_src[s], d_dst[s], d_sizes[s], dst_stride)
+    torch.cuda.synchronize()
+    if rank == 0 and not args.no_verify:
+        from oracle.oracle import Oracle
+
+        po = Oracle().packer(args.packer, args.bps, nch, ns, args.nb)
+        verified = True
+        for s in range(2):
+            for b in sorted({0, B - 1}):
+                want = po.compress(d_src[s][b].cpu().numpy())
+                n = int(d_sizes[s][b])
+                got_b = d_dst[s][b, :n].cpu().numpy().tobytes() if 0 < n <= dst_stride else b""
+                if args.packer == "dct" and ns > 8192:
+                    verified = verified and abs(len(got_b) / max(1, len(want)) - 1) <= 0.01  # FFT path: CR gate, not bytes
+                else:
+                    verified = verified and got_b == want
+        if not verified:
+            sys.stderr.write("bench.py: a produced stream DIFFERS from the oracle\n")
+
+    # per-kernel durations (HIP events on the launch stream), separate profiled pass over both batches
     pk.set_profiling(True)
     acc = {}
-    reps = max(3, min(args.steps, 10))
+    reps = max(4, min(args.steps, 10))
     for i in range(reps):
-        pk.compress_batch(d_src, d_dst[0], d_sizes[0], dst_stride)
+        pk.compress_batch(d_src[i & 1], d_dst[i & 1], d_sizes[i & 1], dst_stride)
         for k, v in pk.stage_times().items():
             acc[k] = acc.get(k, 0.0) + v / reps
     pk.set_profiling(False)
     torch.cuda.synchronize()
-    out_bytes = int(d_sizes[0].sum().item())
+    out_bytes = int((d_sizes[0].sum().item() + d_sizes[1].sum().item()) // 2)
     in_bytes = B * pk.block_bytes
-    samples_per_step = B * nch * ns
+    nb_now = pk.nb
 
     # second denominator: what a plain device copy reaches on this very GPU (bytes read + bytes written)
     copy_gbs = None
@@ -249,34 +372,52 @@ def main():
     if rank == 0:
         dominant = max(acc, key=acc.get)
         alg_bytes = in_bytes + out_bytes  # bytes = input_bytes + output_bytes per launch
-        achieved = alg_bytes / (acc[dominant] * 1e-3) / 1e9
-        traffic = None
+        plane_bytes = B * nb_now * nch * ns  # what the front end hands to the hzr stage
+        # the dominant kernel's OWN algorithmic bytes (what it has to read and write once), over its own duration
+        own = {"preprocess": in_bytes + plane_bytes, "hzr_encode": plane_bytes + out_bytes, "hzr_fused": plane_bytes + out_bytes,
+               "hzr_hist": plane_bytes}.get(dominant, alg_bytes)
+        own = min(own, alg_bytes)  # never more than SURVEY 8(d)'s whole-launch figure
+        achieved = own / (acc[dominant] * 1e-3) / 1e9
+        pipeline_gbs = alg_bytes / (sum(acc.values()) * 1e-3) / 1e9
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        default_shape = (args.packer, B, nch, ns, args.nb, args.bps) == ("xdelta_hzr", 64, 64, 65536, 3, 4)  # what the counters were collected on
-        if default_shape and os.path.exists(tpath):
+        default_shape = (args.packer, args.workload, B, nch, ns, args.nb, args.bps) == ("xdelta_hzr", "c3", 64, 64, 65536, 3, 4)
+        if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant)
+                tj = json.load(open(tpath))
+                if not default_shape:
+                    traffic_note = "counters were collected on the default workload only"
+                elif tj.get("_kernels_sha") != kernels_sha():
+                    traffic_note = "stale: counters collected on other kernel sources (%s)" % tj.get("_kernels_sha")
+                else:
+                    traffic = tj.get(dominant)
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at kernels_sha %s" % tj.get("_kernels_sha")
             except Exception:
                 traffic = None
+        shape = "%dch x %d int%d" % (nch, ns, 8 * args.bps)
+        samples_job = total_blocks * nch * ns
         res = {
-            "metric": "MSamples/s compress (xdelta_hzr, 64ch x 65536 int32)",
-            "value": round(world * samples_per_step * args.steps / dt / 1e6, 1),
+            "metric": "MSamples/s compress (%s, %s)" % (args.packer, shape),
+            "value": round(samples_job * args.steps / dt / 1e6, 1),
             "unit": "MSamples/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if c5 else "weak",
             "vs_baseline": None,
             "dtype": "int%d" % (8 * args.bps),
-            "data": "synthetic",
+            "data": "synthetic (parabolic sine + 4-bit counter-hash noise per SURVEY 8d; hashes differ from the survey's xorshift variant)",
+            "verified": verified,
             "config": {
-                "workload": "%s nb=%d, %d blocks/GPU/step of %dch x %d x int%d (BASELINE configs[2] shape, xdelta_hzr path), device-resident"
-                % (args.packer, args.nb, B, nch, ns, 8 * args.bps),
+                "workload": ("%s nb=%d, %d blocks in total of %s (BASELINE configs[4]), contiguous shards, container pack + gather to rank 0 "
+                             "inside the step, device-resident" % (args.packer, args.nb, total_blocks, shape)) if c5 else
+                            ("%s nb=%d, %d blocks/GPU/step of %s (BASELINE configs[2] shape, xdelta_hzr path), two alternating batches, "
+                             "device-resident" % (args.packer, args.nb, B, shape)),
                 "blocks_per_gpu": B,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
-                "gather": ("every step" if args.gather_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
+                "gather": ("every step, inside the timed region" if payload_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
                 "gathered_bytes": gathered_bytes[0],
                 "gather_ms": round(gather_ms, 3) if gather_ms is not None else None,
                 "parallelism": "shard%d" % world,
@@ -289,20 +430,25 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_note": traffic_note,
+                "kernel_algorithmic_bytes": own,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
-                "pipeline_frac": round(alg_bytes / (sum(acc.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pipeline_gbs": round(pipeline_gbs, 1),
+                "pipeline_frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
                 "device_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
-                "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                "pipeline_frac_of_device_copy": round(pipeline_gbs / copy_gbs, 4) if copy_gbs else None,
             },
         }
         if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(args, d_src[0].cpu().numpy())
+            res["cpu_baseline"] = cpu_baseline(args, d_src[0][0].cpu().numpy())
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     pk.close()
+    if rank == 0 and verified is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

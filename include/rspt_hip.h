@@ -126,21 +126,27 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
 
 /* ---- container: many streams, back to back (what a multi-GPU gather ships) ---
  * layout (little-endian):
- *   u64 magic 'RSPTPACK' | u64 nblocks | u64 payload_bytes | u64 nb (bytes per int32 used by the LAST block)
- *   nblocks x { u64 offset, u64 length }      offsets relative to the payload, 16-byte aligned
+ *   u64 magic 'RSPTPACK' | u64 nblocks | u64 payload_bytes | u64 nb of the LAST stream (low 32 bits), flagged streams (high 32)
+ *   nblocks x { u64 offset, u64 length | nb << 56 | invalid << 63 }   offsets relative to the payload, 16-byte aligned
  *   payload                                    stream b at payload + offset[b], zero padded to 16 bytes
  * rspt_hip_pack_bound() bytes always suffice for d_packed.  d_total (device u64)
  * receives the container length.  The reference keeps nb out of the stream
- * (signal_packer_xdelta_hzr.cpp:39,66); the container carries it so that a
- * consumer of gathered shards can configure its decoder. */
+ * (signal_packer_xdelta_hzr.cpp:39,66) and nb escalates inside a batch (and on every rank
+ * independently), so each index entry carries the plane count of ITS stream: a container decodes
+ * in one call whatever mix of nb it holds.  A stream that did not fit dst_stride at compress time
+ * (bit 63 of its d_sizes entry) becomes an empty entry with the invalid bit set and is counted in
+ * the header; nothing is copied for it.  d_sizes / nblocks must describe the handle's LAST
+ * compress_batch call (that call's per-block nb is what the index records). */
 size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks);
 int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_stride, const uint64_t* d_sizes, size_t nblocks, void* d_packed,
                             uint64_t* d_total, void* stream);
 
-/* Decompress the nblocks streams of a container resident in device memory (16-byte aligned), as laid out above: the
- * consumer side of the gather.  The container's nb field is NOT applied: read it from the header and call
- * rspt_hip_set_nb first when the streams come from another instance.  d_consumed as in the batch form. */
-int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t nblocks, void* d_dst, uint64_t* d_consumed, void* stream);
+/* Decompress the nblocks streams of a container resident in device memory (16-byte aligned, packed_len bytes), as
+ * laid out above: the consumer side of the gather.  Every stream is decoded with the nb of its own index entry; the
+ * handle's nb state is neither used nor changed.  Header and index are checked against packed_len on the device: a
+ * truncated or corrupt container flags its streams (bit 63 of d_consumed[b]) instead of reading out of bounds. */
+int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t packed_len, size_t nblocks, void* d_dst, uint64_t* d_consumed,
+                                   void* stream);
 
 /* The handle's own (non-blocking) stream, as a hipStream_t. */
 void* rspt_hip_stream(rspt_hip_packer* p);

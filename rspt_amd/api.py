@@ -39,15 +39,21 @@ class RsptHipError(RuntimeError):
 
 
 def lib():
-    """Load (building if stale and hipcc is present) librspt_hip.so.  Raises if missing."""
+    """Load librspt_hip.so.  A missing or stale library is rebuilt only where that is safe -- a single process with
+    hipcc at hand; under a launcher (RANK set: the ranks of a torchrun job) a stale library is an error, never a
+    concurrent compile.  Raises if the library cannot be had: there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
     path = _build.LIB
     if os.environ.get("RSPT_HIP_LIB"):  # A/B timing of two builds in one session (tools/ab.sh); not a fallback
         path = os.environ["RSPT_HIP_LIB"]
-    elif os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
-        path = _build.build()
+    elif _build.stale():
+        if "RANK" in os.environ:
+            raise RuntimeError("rspt_amd: %s is missing or older than its sources; run `python __graft_entry__.py` (build()) "
+                               "before launching ranks" % path)
+        if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            path = _build.build()
     if not os.path.exists(path):
         raise RuntimeError("rspt_amd: %s is missing and cannot be built here; there is no CPU fallback" % path)
     # One HIP runtime per process: torch ships its own libamdhip64 and the batch entry points take torch
@@ -75,7 +81,7 @@ def lib():
     L.rspt_hip_decompress_batch_dev.restype = C.c_int
     L.rspt_hip_decompress_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rspt_hip_decompress_packed_dev.restype = C.c_int
-    L.rspt_hip_decompress_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rspt_hip_decompress_packed_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.rspt_hip_synchronize.restype, L.rspt_hip_synchronize.argtypes = C.c_int, [C.c_void_p]
     L.rspt_hip_stream.restype, L.rspt_hip_stream.argtypes = C.c_void_p, [C.c_void_p]
     L.rspt_hip_pack_bound.restype, L.rspt_hip_pack_bound.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t]
@@ -193,23 +199,23 @@ class SignalPacker:
         self._check("rspt_hip_decompress_batch_dev", rc)
         return d_out, d_consumed
 
-    def decompress_packed(self, d_packed, d_out=None, d_consumed=None, stream=None, apply_nb=True):
+    def decompress_packed(self, d_packed, d_out=None, d_consumed=None, stream=None, nbytes=None):
         """Decompress every stream of a container (what pack_batch / the multi-GPU gather produce) on the device.
-        Reads the 32-byte header to the host for the block count and nb (a synchronisation)."""
+        Each stream is decoded with the nb of its own index entry.  Reads the 32-byte header to the host for the block
+        count (a synchronisation).  `nbytes`: container length if shorter than the tensor."""
         import torch
 
         head = d_packed[:32].cpu().numpy().view(np.uint64)
         if int(head[0]) != 0x4B43415054505352:
             raise ValueError("not an RSPTPACK container")
-        nblocks, nb = int(head[1]), int(head[3])
-        if apply_nb and self.kind == KINDS["xdelta_hzr"]:
-            self.set_nb(nb)
+        nblocks = int(head[1])
         if d_out is None:
             d_out = torch.empty((nblocks, self.block_bytes), dtype=torch.uint8, device=d_packed.device)
         if d_consumed is None:
             d_consumed = torch.empty(nblocks, dtype=torch.int64, device=d_packed.device)
         st = stream if stream is not None else torch.cuda.current_stream(d_packed.device).cuda_stream
-        rc = self._L.rspt_hip_decompress_packed_dev(self._h, d_packed.data_ptr(), nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
+        plen = int(nbytes) if nbytes is not None else d_packed.numel()
+        rc = self._L.rspt_hip_decompress_packed_dev(self._h, d_packed.data_ptr(), plen, nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
         self._check("rspt_hip_decompress_packed_dev", rc)
         return d_out, d_consumed
 

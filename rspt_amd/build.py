@@ -1,8 +1,14 @@
 """Build the gfx950 shared library in-tree: rspt_amd/librspt_hip.so.
 
 hipcc cross-compiles without a GPU; the built .so is git-ignored but travels to
-the GPU box with the gpurun snapshot.
+the GPU box with the gpurun snapshot.  Staleness is decided by a content
+fingerprint of the sources (kept beside the library), not by mtimes -- a snapshot
+copy need not preserve those.  Concurrent callers (the ranks of a torchrun job)
+serialise on a file lock and the library is published with an atomic rename, so
+nobody ever maps a half-written file.
 """
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,27 +16,50 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librspt_hip.so")
+STAMP = LIB + ".src-sha"
 SOURCES = ["rspt_hip.hip", "signal_packer_hip.cpp"]
-DEPS = SOURCES + ["common.hpp", "preprocess.hip", "hzr_kernels.hip", "transforms.hip", "decode.hip"]
+DEPS = SOURCES + ["common.hpp", "preprocess.hip", "hzr_kernels.hip", "hzr_fused.hip", "transforms.hip", "decode.hip", "filter.hip"]
 INCLUDES = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("rspt_hip.h", "signal_packer.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def fingerprint():
+    h = hashlib.sha256(" ".join(FLAGS + sorted(os.environ.get("RSPT_EXTRA_FLAGS", "").split())).encode())
+    for p in [os.path.join(CSRC, f) for f in DEPS] + INCLUDES:
+        if os.path.exists(p):
+            h.update(os.path.basename(p).encode())
+            h.update(open(p, "rb").read())
+    return h.hexdigest()
+
+
+def stale():
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in [os.path.join(CSRC, f) for f in DEPS] + INCLUDES)
+    return open(STAMP).read().strip() != fingerprint()
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
+    if not force and not stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", LIB]
-    cmd += [os.path.join(CSRC, f) for f in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not force and not stale():  # another process built it while we waited
+                return LIB
+            fp = fingerprint()
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = "%s.tmp.%d" % (LIB, os.getpid())
+            cmd = [hipcc] + FLAGS + os.environ.get("RSPT_EXTRA_FLAGS", "").split() + ["-o", tmp]
+            cmd += [os.path.join(CSRC, f) for f in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+            with open(STAMP + ".tmp", "w") as f:
+                f.write(fp + "\n")
+            os.replace(STAMP + ".tmp", STAMP)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB
 
 

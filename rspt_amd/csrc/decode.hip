@@ -24,32 +24,53 @@ __device__ __forceinline__ uint32_t ld_le32(const uint8_t* p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-// one thread per (block, plane)
 // Where stream b starts and how many bytes it may span: fixed stride, or the (offset, length) index of a container
 // (include/rspt_hip.h: 'RSPTPACK'; `src` then points at the container's payload).
+constexpr uint64_t kIdxLenMask = (1ull << 56) - 1ull;  // index length word: length | nb << 56 | invalid << 63
 __device__ __forceinline__ const uint8_t* stream_base(const uint8_t* src, uint64_t src_stride, const uint64_t* __restrict__ pidx, uint32_t b,
                                                      uint64_t& limit) {
     if (pidx) {
-        limit = pidx[2 * b + 1];
+        limit = pidx[2 * b + 1] & kIdxLenMask;
         return src + pidx[2 * b];
     }
     limit = src_stride;
     return src + (size_t)b * src_stride;
 }
 
+// one thread per (block, plane).  Container form: the header and the index entry are validated against the container's
+// byte length before anything is read through them (a truncated or corrupt gather flags the stream instead of reading
+// out of bounds), and the stream's own nb comes from its index entry -- streams of one container may differ (escalation
+// inside a batch, shards of independently escalating ranks).  dec_nb[b] = planes of stream b, for the kernels that follow.
 __global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride_in, uint32_t nblocks, Geom g, const uint32_t* __restrict__ nb_state,
                             uint64_t* __restrict__ blk_off, uint64_t* __restrict__ consumed, uint8_t* __restrict__ means,
-                            const uint64_t* __restrict__ pidx, uint32_t* __restrict__ dec_counter) {
+                            const uint64_t* __restrict__ pidx, uint32_t* __restrict__ dec_counter, uint64_t packed_len,
+                            uint32_t* __restrict__ dec_nb) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) *dec_counter = 0;  // k_dec_block's work queue
     const uint32_t b = t / kMaxPlanes, k = t % kMaxPlanes;
     if (b >= nblocks) return;
-    const uint32_t nb = *nb_state;
+    uint32_t nb = *nb_state;
+    bool bad = false;
+    if (pidx) {
+        const uint64_t* head = pidx - 4;  // magic, nblocks, payload bytes, nb
+        const uint64_t payload = head[2];
+        const uint64_t off = pidx[2 * b], lw = pidx[2 * b + 1], len = lw & kIdxLenMask;
+        if (head[0] != 0x4B43415054505352ull || head[1] != nblocks || 32ull + 16ull * nblocks + payload > packed_len || (lw >> 63) ||
+            off > payload || len > payload - off)
+            bad = true;
+        const uint32_t nbi = (uint32_t)(lw >> 56) & 0xFu;
+        if (nbi >= 1 && nbi <= 4) nb = nbi;  // (0: a container written without per-stream nb -> the handle's state)
+    }
+    if (k == 0) dec_nb[b] = bad ? 0u : nb;
+    if (bad) {
+        if (k == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+        for (uint32_t j = 0; j < g.nblk; ++j) blk_off[hb_index(g, b, k, 0) + j] = ~0ull;
+        return;
+    }
     if (k >= nb) return;
     uint64_t src_stride;  // bytes stream b may span
     const uint8_t* s = stream_base(src, src_stride_in, pidx, b, src_stride);
     uint64_t pos = 1ull + g.hdr_len;
-    bool bad = false;
     for (uint32_t kk = 0; kk < k; ++kk) {
         if (pos + 4 > src_stride) {
             bad = true;
@@ -236,12 +257,12 @@ __shared__ DecLds g_dec;
 
 // one hzr block (plane k, block j of stream b) by one 1024-thread workgroup
 __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, const uint8_t* __restrict__ src, uint64_t src_stride, const Geom& g,
-                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
+                                          const uint32_t* __restrict__ dec_nb, const uint64_t* __restrict__ blk_off,
                                           uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
                                           unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
                                           const uint64_t* __restrict__ pidx) {
     DecLds& d = g_dec;
-    if (k >= *nb_state) return;
+    if (k >= dec_nb[b]) return;
     const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
     const uint32_t hb = hb_index(g, b, k, j);
 #define DEC_STAMP(i) do { if (stamps && tid == 0 && hb < 512u) stamps[hb * 8u + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -567,7 +588,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
 // Persistent grid over the hzr blocks, plane-major (the dense plane-0 blocks first): the first block of a workgroup is
 // static, the rest come from a counter.
 __global__ __launch_bounds__(kDecThreads, 8) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
-                                                          const uint32_t* __restrict__ nb_state, const uint64_t* __restrict__ blk_off,
+                                                          const uint32_t* __restrict__ dec_nb, const uint64_t* __restrict__ blk_off,
                                                           uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
                                                           unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
                                                           const uint64_t* __restrict__ pidx, uint32_t* __restrict__ counter, uint32_t total) {
@@ -580,7 +601,7 @@ __global__ __launch_bounds__(kDecThreads, 8) void k_dec_block(const uint8_t* __r
         const uint32_t i = s_next;
         if (i >= total) break;
         const uint32_t k = i / per_plane, x = i - k * per_plane;
-        dec_block(k, x % g.nblk, x / g.nblk, src, src_stride, g, nb_state, blk_off, planes, consumed, stamps, vcc, pidx);
+        dec_block(k, x % g.nblk, x / g.nblk, src, src_stride, g, dec_nb, blk_off, planes, consumed, stamps, vcc, pidx);
     }
 }
 
@@ -639,12 +660,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // PASS 0: tile XOR totals.  PASS 1: tile sums of o+128 (needs XOR carries).
 // PASS 2: final values p -> planar.  XDELTA=false: p = v, single pass.
 template <int PASS, bool XDELTA>
-__global__ __launch_bounds__(256) void k_inv_tile(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nb_state,
+__global__ __launch_bounds__(256) void k_inv_tile(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ dec_nb,
                                                  uint32_t ntile, uint32_t* __restrict__ txor, uint32_t* __restrict__ tsum,
                                                  int32_t* __restrict__ planar) {
     __shared__ uint32_t s_w[4];
     const uint32_t tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const uint32_t nb = *nb_state;
+    const uint32_t nb = dec_nb[b];  // planes of THIS stream (k_dec_frame)
     const uint32_t i0 = tile * kInvTile + tid * 16;
     const uint32_t cnt = i0 < g.N ? min(16u, g.N - i0) : 0u;
     uint32_t v[16];

@@ -1535,20 +1535,32 @@ __global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(uint8_t* __re
 // container packing (rspt_hip_pack_batch_dev)
 // ===========================================================================
 constexpr uint64_t kPackMagic = 0x4B43415054505352ull;  // "RSPTPACK"
-constexpr uint32_t kPackHead = 32;                      // magic, nblocks, payload bytes, nb
+constexpr uint32_t kPackHead = 32;                      // magic, nblocks, payload bytes, nb | bad << 32
+constexpr uint64_t kPackLenMask = (1ull << 56) - 1ull;  // index length word: length | nb << 56 | invalid << 63
 
+// The index is self-describing per stream: nb escalates inside a batch and every rank escalates on its own, so the
+// plane count of stream i (nbuse[i], the reference's nr_bytes_to_compress_ at that call) travels in its length word.
+// A stream that did not fit dst_stride (bit 63 of sizes[i]: nothing was written) becomes an empty, flagged entry.
 __global__ __launch_bounds__(1024) void k_pack_index(const uint64_t* __restrict__ sizes, uint32_t nblocks, const uint32_t* __restrict__ nb_state,
-                                                    uint8_t* __restrict__ packed, uint64_t* __restrict__ total) {
+                                                    const uint32_t* __restrict__ nbuse, uint8_t* __restrict__ packed,
+                                                    uint64_t* __restrict__ total) {
     __shared__ uint64_t s_w[16];
     __shared__ uint64_t s_carry;
+    __shared__ uint32_t s_bad;
     uint64_t* head = reinterpret_cast<uint64_t*>(packed);
     uint64_t* index = head + 4;
     const uint32_t tid = threadIdx.x, l = tid & 63, w = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) {
+        s_carry = 0;
+        s_bad = 0;
+    }
     __syncthreads();
     for (uint32_t base = 0; base < nblocks; base += 1024) {
         const uint32_t i = base + tid;
-        const uint64_t len = i < nblocks ? (sizes[i] & ~(1ull << 63)) : 0ull;
+        const uint64_t sz = i < nblocks ? sizes[i] : 0ull;
+        const bool bad = (sz >> 63) != 0;
+        const uint64_t len = bad ? 0ull : sz;
+        if (bad) atomicAdd(&s_bad, 1u);
         const uint64_t v = (len + 15ull) & ~15ull;
         uint64_t inc = v;
 #pragma unroll
@@ -1565,7 +1577,7 @@ __global__ __launch_bounds__(1024) void k_pack_index(const uint64_t* __restrict_
         }
         if (i < nblocks) {
             index[2 * i] = pre + inc - v;
-            index[2 * i + 1] = len;
+            index[2 * i + 1] = len | ((uint64_t)(nbuse[i] & 0xFu) << 56) | (bad ? (1ull << 63) : 0ull);
         }
         __syncthreads();
         if (tid == 0) s_carry = tot;
@@ -1575,7 +1587,7 @@ __global__ __launch_bounds__(1024) void k_pack_index(const uint64_t* __restrict_
         head[0] = kPackMagic;
         head[1] = nblocks;
         head[2] = s_carry;
-        head[3] = *nb_state;
+        head[3] = (uint64_t)*nb_state | ((uint64_t)s_bad << 32);
         *total = kPackHead + 16ull * nblocks + s_carry;
     }
 }
@@ -1585,7 +1597,7 @@ __global__ __launch_bounds__(256) void k_pack_copy(const uint8_t* __restrict__ d
                                                   uint8_t* __restrict__ packed) {
     const uint32_t b = blockIdx.y;
     const uint64_t* index = reinterpret_cast<const uint64_t*>(packed) + 4;
-    const uint64_t off = index[2 * b], len = index[2 * b + 1];
+    const uint64_t off = index[2 * b], len = index[2 * b + 1] & kPackLenMask;  // (0 for a flagged stream: nothing to copy)
     const uint8_t* s = dst + (size_t)b * dst_stride;
     uint8_t* o = packed + kPackHead + 16ull * nblocks + off;
     const uint64_t units = (len + 15) >> 4;

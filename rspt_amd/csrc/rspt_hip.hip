@@ -112,6 +112,7 @@ struct rspt_hip_packer {
     int32_t* planar = nullptr;     // [cap][N] (transform packers, decode)
     uint32_t* needmask = nullptr;  // [cap]
     uint32_t* nbuse = nullptr;     // [cap]
+    uint32_t* dec_nb = nullptr;    // [cap] decode: planes of each stream (container index entry, else nb_state)
     uint32_t* work_ctr = nullptr;  // [16] work counter of the persistent k_hist at 0, the WorkQueues of k_encode from 4 (zeroed per call)
     uint32_t* big_list = nullptr;  // [cap*4*nblk] hzr blocks for the workgroup-per-block encoder (filled by k_layout)
     uint32_t* small_list = nullptr;  // [cap*4*nblk] hzr blocks for the wave-per-block encoder
@@ -347,6 +348,8 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planes);
     hipFree(p->planar);
     hipFree(p->nbuse);
+    hipFree(p->dec_nb);
+    p->dec_nb = nullptr;
     hipFree(p->nzflag);
     hipFree(p->plane_dirty);
     p->plane_dirty = nullptr;
@@ -629,6 +632,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     bool ok = true;
     ok &= hipMalloc(&p->planes, max_blocks * kMaxPlanes * g.plane_stride + 4096) == hipSuccess;
     ok &= hipMalloc(&p->nbuse, max_blocks * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->dec_nb, max_blocks * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->plane_dirty, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
@@ -795,10 +799,11 @@ size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks) {
 int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_stride, const uint64_t* d_sizes, size_t nblocks, void* d_packed,
                             uint64_t* d_total, void* stream) {
     if (!p || !d_dst || !d_sizes || !d_packed || !d_total || nblocks == 0 || nblocks > 65535) return RSPT_HIP_ERR_ARG;
+    if (nblocks > p->cap_blocks) return RSPT_HIP_ERR_ARG;  // the per-stream nb comes from the handle's last compress call of >= nblocks blocks
     if ((reinterpret_cast<uintptr_t>(d_dst) & 15) || (dst_stride & 15) || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return RSPT_HIP_ERR_ARG;
     HIPCHK(p, hipSetDevice(p->device));
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_pack_index, dim3(1), dim3(1024), 0, st, d_sizes, (uint32_t)nblocks, p->nb_state, (uint8_t*)d_packed, d_total);
+    hipLaunchKernelGGL(k_pack_index, dim3(1), dim3(1024), 0, st, d_sizes, (uint32_t)nblocks, p->nb_state, p->nbuse, (uint8_t*)d_packed, d_total);
     hipLaunchKernelGGL(k_pack_copy, dim3(32, (unsigned)nblocks), dim3(256), 0, st, (const uint8_t*)d_dst, (uint64_t)dst_stride, (uint32_t)nblocks,
                        (uint8_t*)d_packed);
     HIPCHK(p, hipGetLastError());
@@ -882,23 +887,26 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
     return RSPT_HIP_OK;
 }
 
-static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t nblocks, void* d_dst,
-                          uint64_t* d_consumed, void* stream);
+static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,
+                          void* d_dst, uint64_t* d_consumed, void* stream);
 
 int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, size_t nblocks, void* d_dst, uint64_t* d_consumed,
                                   void* stream) {
-    return decompress_dev(p, d_src, src_stride, nullptr, nblocks, d_dst, d_consumed, stream);
+    return decompress_dev(p, d_src, src_stride, nullptr, 0, nblocks, d_dst, d_consumed, stream);
 }
 
-int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t nblocks, void* d_dst, uint64_t* d_consumed, void* stream) {
+int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t packed_len, size_t nblocks, void* d_dst, uint64_t* d_consumed,
+                                   void* stream) {
     if (!d_packed || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return RSPT_HIP_ERR_ARG;
+    if (packed_len < 32 + 16 * nblocks) return RSPT_HIP_ERR_CORRUPT;  // header + index must be there before the device reads them
     const uint8_t* base = (const uint8_t*)d_packed;
     // header 32 bytes, index 16 bytes per stream, then the payload the offsets are relative to
-    return decompress_dev(p, base + 32 + 16 * nblocks, 0, reinterpret_cast<const uint64_t*>(base + 32), nblocks, d_dst, d_consumed, stream);
+    return decompress_dev(p, base + 32 + 16 * nblocks, 0, reinterpret_cast<const uint64_t*>(base + 32), packed_len, nblocks, d_dst, d_consumed,
+                          stream);
 }
 
-static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t nblocks, void* d_dst,
-                          uint64_t* d_consumed, void* stream) {
+static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,
+                          void* d_dst, uint64_t* d_consumed, void* stream) {
     if (!p || !d_src || !d_dst || !d_consumed || nblocks == 0) return RSPT_HIP_ERR_ARG;
     int rc = rspt_hip_reserve(p, nblocks);
     if (rc) return rc;
@@ -911,25 +919,25 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         const uint8_t* src = (const uint8_t*)d_src;
         HIPCHK(p, hipMemsetAsync(d_consumed, 0, nblocks * sizeof(uint64_t), st));
         hipLaunchKernelGGL(k_dec_frame, dim3((B * kMaxPlanes + 63) / 64), dim3(64), 0, st, src, (uint64_t)src_stride, B, g, p->nb_state, p->blk_off,
-                           d_consumed, p->means, pidx, p->nb_state + 2);
+                           d_consumed, p->means, pidx, p->nb_state + 2, (uint64_t)packed_len, p->dec_nb);
         {
             // persistent: block costs differ 10x (dense plane 0 against light planes) and the dispatcher places workgroup i
             // on XCD i % 8 in order, so a plain grid ran its second half at a quarter of the slots (tools/census_decode.py)
             const uint32_t total = g.nblk * B * kMaxPlanes;
             const uint32_t want = 2u * (uint32_t)p->num_cu;  // two 1024-thread workgroups (76 KiB of LDS each) per CU
-            hipLaunchKernelGGL(k_dec_block, dim3(want < total ? want : total), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->nb_state, p->blk_off,
+            hipLaunchKernelGGL(k_dec_block, dim3(want < total ? want : total), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->dec_nb, p->blk_off,
                                p->planes, d_consumed, p->ablate ? p->stamps : nullptr, p->verify ? p->crc : nullptr, pidx, p->nb_state + 2, total);
         }
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
         if (xd) {
-            hipLaunchKernelGGL((k_inv_tile<0, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_tile<0, true>), tg, dim3(256), 0, st, p->planes, g, p->dec_nb, p->ntile, p->txor, p->tsum, p->planar);
             hipLaunchKernelGGL((k_inv_scan_tiles<true>), dim3(B), dim3(1024), 0, st, p->txor, p->ntile);
-            hipLaunchKernelGGL((k_inv_tile<1, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_tile<1, true>), tg, dim3(256), 0, st, p->planes, g, p->dec_nb, p->ntile, p->txor, p->tsum, p->planar);
             hipLaunchKernelGGL((k_inv_scan_tiles<false>), dim3(B), dim3(1024), 0, st, p->tsum, p->ntile);
-            hipLaunchKernelGGL((k_inv_tile<2, true>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_tile<2, true>), tg, dim3(256), 0, st, p->planes, g, p->dec_nb, p->ntile, p->txor, p->tsum, p->planar);
         } else {
-            hipLaunchKernelGGL((k_inv_tile<2, false>), tg, dim3(256), 0, st, p->planes, g, p->nb_state, p->ntile, p->txor, p->tsum, p->planar);
+            hipLaunchKernelGGL((k_inv_tile<2, false>), tg, dim3(256), 0, st, p->planes, g, p->dec_nb, p->ntile, p->txor, p->tsum, p->planar);
         }
         const int32_t* final_planar = p->planar;
         if (g.kind == RSPT_HIP_KIND_HADAMARD) {

@@ -23,35 +23,45 @@ def shard_range(nblocks_total, rank, world):
     return first, last - first
 
 
+LEN_MASK = (1 << 56) - 1  # index length word: length | nb << 56 | invalid << 63
+
+
 def pack_container(streams, nb):
+    """nb: one int for all streams, or one per stream (nb escalates inside a batch)"""
     n = len(streams)
+    nbs = [nb] * n if isinstance(nb, int) else list(nb)
     offs, pos = [], 0
     for s in streams:
         offs.append(pos)
         pos += (len(s) + 15) & ~15
     out = bytearray(PACK_HEAD + 16 * n + pos)
-    struct.pack_into("<QQQQ", out, 0, PACK_MAGIC, n, pos, nb)
+    struct.pack_into("<QQQQ", out, 0, PACK_MAGIC, n, pos, nbs[-1] if n else 0)
     for i, s in enumerate(streams):
-        struct.pack_into("<QQ", out, PACK_HEAD + 16 * i, offs[i], len(s))
+        struct.pack_into("<QQ", out, PACK_HEAD + 16 * i, offs[i], len(s) | (nbs[i] << 56))
         base = PACK_HEAD + 16 * n + offs[i]
         out[base : base + len(s)] = s
     return bytes(out)
 
 
-def unpack_container(buf):
-    """-> (list of streams, nb)"""
+def unpack_container(buf, per_stream_nb=False):
+    """-> (list of streams, nb of the last stream); per_stream_nb=True: (streams, [nb per stream]).
+    A stream flagged invalid (it did not fit its slot at compress time) comes back as None."""
     buf = bytes(buf)
-    magic, n, payload, nb = struct.unpack_from("<QQQQ", buf, 0)
+    magic, n, payload, nbw = struct.unpack_from("<QQQQ", buf, 0)
     if magic != PACK_MAGIC:
         raise ValueError("not an RSPTPACK container")
     base = PACK_HEAD + 16 * n
     if len(buf) < base + payload:
         raise ValueError("truncated container")
-    out = []
+    out, nbs = [], []
     for i in range(n):
-        off, ln = struct.unpack_from("<QQ", buf, PACK_HEAD + 16 * i)
-        out.append(buf[base + off : base + off + ln])
-    return out, nb
+        off, lw = struct.unpack_from("<QQ", buf, PACK_HEAD + 16 * i)
+        ln = lw & LEN_MASK
+        if off + ln > payload:
+            raise ValueError("container index entry %d points outside the payload" % i)
+        out.append(None if lw >> 63 else buf[base + off : base + off + ln])
+        nbs.append((lw >> 56) & 0xF)
+    return (out, nbs) if per_stream_nb else (out, nbw & 0xFFFFFFFF)
 
 
 def gather_containers(packed, total, dst=0, group=None, recv_bufs=None):

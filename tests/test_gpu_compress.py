@@ -154,13 +154,96 @@ def test_pack_batch_container(api, orc):
     torch.cuda.synchronize()
     total = int(d_total.item())
     assert total <= pk.pack_bound(len(blocks))
-    streams, nb = shard.unpack_container(d_packed[:total].cpu().numpy().tobytes())
+    cont = d_packed[:total].cpu().numpy().tobytes()
+    streams, nbs = shard.unpack_container(cont, per_stream_nb=True)
     po = orc.packer("xdelta_hzr", bps, nch, ns, 1)
-    want = [po.compress(b) for b in blocks]
+    want, want_nb = [], []
+    for b in blocks:
+        want.append(po.compress(b))
+        want_nb.append(orc.packer_nb(po))  # nr_bytes_to_compress_ after this call = the planes of this stream
     assert streams == want
-    assert nb == orc.packer_nb(po) == pk.nb
+    assert nbs == want_nb and len(set(nbs)) > 1, nbs  # nb escalates INSIDE this batch: the index records it per stream
+    assert shard.unpack_container(cont)[1] == orc.packer_nb(po) == pk.nb
     # host-side packer produces the same bytes
-    assert shard.pack_container(want, nb) == d_packed[:total].cpu().numpy().tobytes()
+    assert shard.pack_container(want, want_nb) == cont
+    # and the mixed-nb container decodes in ONE call on another instance, whatever that one's nb state is
+    other = api.new_xdelta_hzr(bps, nch, ns, 4)
+    out, used = other.decompress_packed(d_packed, nbytes=total)
+    torch.cuda.synchronize()
+    assert torch.equal(out, d_src) and used.tolist() == [len(x) for x in want]
+    assert other.nb == 4
+    other.close()
+    pk.close()
+
+
+def test_pack_batch_skips_streams_that_did_not_fit(api, orc):
+    """A block whose stream exceeds dst_stride is flagged in d_sizes (bit 63) and nothing is written for it: the container
+    must carry an empty, flagged entry -- not `len` bytes copied out of its neighbour's slot."""
+    import torch
+
+    from rspt_amd import shard
+
+    nch, ns, bps = 2, 3000, 4
+    quiet = [cases._rand_native(nch, ns, bps, 900 + i, 5, walk=True) for i in range(3)]
+    loud = cases._rand_native(nch, ns, bps, 950, 1 << 22, walk=False)
+    blocks = [quiet[0], loud, quiet[1], quiet[2], loud]  # (the last one too: its copy would run past the allocation)
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 3)
+    want = [po.compress(b) for b in blocks]
+    stride = (max(len(want[0]), len(want[2]), len(want[3])) + 64 + 15) // 16 * 16
+    assert len(want[1]) > stride
+    pk = api.new_xdelta_hzr(bps, nch, ns, 3)
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    d_dst = torch.zeros((len(blocks), stride), dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(len(blocks), dtype=torch.int64, device="cuda")
+    pk.compress_batch(d_src, d_dst, d_sizes, stride)
+    d_packed, d_total = pk.pack_batch(d_dst, d_sizes)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy().view(np.uint64)
+    assert [int(x >> 63) for x in sizes] == [0, 1, 0, 0, 1]
+    total = int(d_total.item())
+    cont = d_packed[:total].cpu().numpy().tobytes()
+    streams, _ = shard.unpack_container(cont)
+    assert streams == [want[0], None, want[2], want[3], None]
+    assert int(np.frombuffer(cont[24:32], dtype=np.uint64)[0]) >> 32 == 2  # flagged streams counted in the header
+    # decode: the good streams come back, the flagged ones are reported (bit 63), nothing is read out of bounds
+    out, used = pk.decompress_packed(d_packed, nbytes=total)
+    torch.cuda.synchronize()
+    u = used.cpu().numpy().view(np.uint64)
+    assert [int(x >> 63) for x in u] == [0, 1, 0, 0, 1]
+    for i in (0, 2, 3):
+        assert out[i].cpu().numpy().tobytes() == blocks[i].tobytes() and int(u[i]) == len(want[i])
+    pk.close()
+
+
+def test_decompress_packed_rejects_a_damaged_container(api, orc):
+    """truncated payload / index entry pointing outside / wrong block count: flagged on the device, never an out-of-bounds read"""
+    import torch
+
+    nch, ns, bps, B = 3, 2000, 4, 4
+    blocks = [cases._rand_native(nch, ns, bps, 970 + i, 200, walk=True) for i in range(B)]
+    pk = api.new_xdelta_hzr(bps, nch, ns, 3)
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    d_dst, d_sizes = pk.compress_batch(d_src)
+    d_packed, d_total = pk.pack_batch(d_dst, d_sizes)
+    torch.cuda.synchronize()
+    total = int(d_total.item())
+    good = d_packed[:total].clone()
+    out, used = pk.decompress_packed(good)
+    torch.cuda.synchronize()
+    assert torch.equal(out, d_src)
+    # (a) the container is said to be shorter than its header claims
+    _, used = pk.decompress_packed(good, nbytes=total - 16)
+    torch.cuda.synchronize()
+    assert all(int(x) >> 63 for x in used.cpu().numpy().view(np.uint64))
+    # (b) one index entry points past the payload: that stream is flagged, the others decode
+    bad = good.clone()
+    idx = bad[32 : 32 + 16 * B].view(torch.int64)
+    idx[2 * 2] = total  # offset of stream 2
+    out, used = pk.decompress_packed(bad)
+    torch.cuda.synchronize()
+    u = used.cpu().numpy().view(np.uint64)
+    assert [int(x >> 63) for x in u] == [0, 0, 1, 0]
+    assert torch.equal(out[0], d_src[0]) and torch.equal(out[3], d_src[3])
     pk.close()
 
 

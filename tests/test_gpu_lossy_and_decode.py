@@ -180,10 +180,10 @@ def test_decompress_straight_from_a_container(api, orc):
     pk.compress_batch(d_src, d_dst, d_sizes, stride)
     packed, total = pk.pack_batch(d_dst, d_sizes)
     torch.cuda.synchronize()
-    other = api.new_xdelta_hzr(4, nch, ns, 1)  # another instance: nb comes from the container
+    other = api.new_xdelta_hzr(4, nch, ns, 1)  # another instance: every stream's nb comes from its index entry
     out, used = other.decompress_packed(packed[: int(total.item())])
     torch.cuda.synchronize()
     assert torch.equal(out, d_src) and torch.equal(used, d_sizes)
-    assert other.nb == pk.nb
+    assert other.nb == 1  # the handle's own state is neither used nor changed
     pk.close()
     other.close()

@@ -38,8 +38,11 @@ def _worker(rank, world, port, q):
     orc = Oracle()
     pk = orc.packer("xdelta_hzr", BPS, NCH, NS, 1)
     blocks = _blocks()[first : first + count]
-    streams = [pk.compress(b) for b in blocks]
-    cont = shard.pack_container(streams, orc.packer_nb(pk))
+    streams, nbs = [], []
+    for b in blocks:
+        streams.append(pk.compress(b))
+        nbs.append(orc.packer_nb(pk))  # the planes of THIS stream (nb escalates inside a shard)
+    cont = shard.pack_container(streams, nbs)
     packed = torch.frombuffer(bytearray(cont), dtype=torch.uint8)
     total = torch.tensor([len(cont)], dtype=torch.int64)
     got = shard.gather_containers(packed, total, dst=0)
@@ -93,15 +96,19 @@ def test_gather_world2_gloo():
     blocks = _blocks()
     pos = 0
     for r, c in enumerate(conts):
-        streams, nb = shard.unpack_container(c)
+        streams, nbs = shard.unpack_container(c, per_stream_nb=True)
         first, count = shard.shard_range(NBLOCKS, r, 2)
         assert first == pos and len(streams) == count
         pk = orc.packer("xdelta_hzr", BPS, NCH, NS, 1)
-        want = [pk.compress(b) for b in blocks[first : first + count]]
-        assert streams == want and nb == orc.packer_nb(pk)
-        # and they decode back with a decoder configured from the container's nb
-        dec = orc.packer("xdelta_hzr", BPS, NCH, NS, nb)
-        for s_, b in zip(streams[-1:], blocks[first + count - 1 : first + count]):
+        want, want_nb = [], []
+        for b in blocks[first : first + count]:
+            want.append(pk.compress(b))
+            want_nb.append(orc.packer_nb(pk))
+        assert streams == want and nbs == want_nb and shard.unpack_container(c)[1] == orc.packer_nb(pk)
+        # EVERY stream decodes back with a decoder configured from its own index entry (each rank escalates on its own,
+        # and inside its shard)
+        for s_, nb_, b in zip(streams, nbs, blocks[first : first + count]):
+            dec = orc.packer("xdelta_hzr", BPS, NCH, NS, nb_)
             assert dec.decompress(s_)[0] == b.tobytes()
         pos += count
     assert pos == NBLOCKS
