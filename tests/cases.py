@@ -194,3 +194,10 @@ def packer_cases():
     add("dct_rand_2x37", "dct", 4, 2, 37, 2, _rand_native(2, 37, 4, 48, 3000), "full")
     add("dct_i16_4x128", "dct", 2, 4, 128, 2, _rand_native(4, 128, 2, 49, 3000), "full")
     return C
+
+
+def dct_big_cases():
+    """dct beyond the dense-table limit of the GPU build (ns > 8192) where the REAL reference can still run (n x n float
+    table: 1 GiB at 16384; ~20 s per case here).  The reference's full stream is the fixture: the FFT path is held to it."""
+    return [dict(name="synth2x16384_dct", kind="dct", bps=4, nch=2, ns=16384, nb=2,
+                 data=np.ascontiguousarray(synth.synth_native(2, 16384, block_index=11, ecg=True).numpy().reshape(-1)))]

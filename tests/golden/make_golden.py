@@ -72,6 +72,20 @@ def main():
         out["packers"][c["name"]] = e
         print("%-28s %-10s size %8d nb %d->%d fnv %08x %s" % (c["name"], c["kind"], len(s), c["nb"], e["final_nb"], e["fnv1a"], "prdn %s" % e["prdn"] if "prdn" in e else ""))
         pk.close()
+    out["dct_big"] = {}
+    for c in cases.dct_big_cases():
+        pk = ref.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+        s = pk.compress(c["data"])
+        dec, used, rc = pk.decompress(s)
+        assert used == len(s) and rc == 0
+        out["dct_big"][c["name"]] = {
+            "kind": c["kind"], "bps": c["bps"], "nch": c["nch"], "ns": c["ns"], "nb": c["nb"],
+            "in_crc32": zlib.crc32(c["data"].tobytes()), "size": len(s), "fnv1a": orc.fnv1a(s), "crc32": zlib.crc32(s),
+            "decoded_crc32": zlib.crc32(dec), "prdn": orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"]),
+            "stream": s.hex(),  # the whole stream: the GPU's FFT path is compared coefficient by coefficient
+        }
+        print("%-28s %-10s size %8d prdn %s" % (c["name"], c["kind"], len(s), out["dct_big"][c["name"]]["prdn"]))
+        pk.close()
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "golden.json"))

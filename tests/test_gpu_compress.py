@@ -424,3 +424,39 @@ def test_full_size_dense_then_quiet_on_one_handle(api, orc):
             assert got == want, describe_mismatch(got, want)
         assert pk.nb == orc.packer_nb(po) == 4
     pk.close()
+
+
+@pytest.mark.parametrize("nblocks,first", [(128, 896), (1024, 0)])
+def test_baseline_config5_scale(api, orc, nblocks, first):
+    """BASELINE configs[4]: 1024 independent 12ch x 8192 blocks -- the whole job in ONE launch, and the last rank's shard of
+    an 8-GPU run (128 blocks from block 896).  Two hzr blocks per plane (65536 + 32768 bytes) that straddle channels
+    (SURVEY D4); thousands of hzr blocks through the work queues and the stream-offset scan.  Every stream against the oracle,
+    then the whole batch back through the GPU decoder."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns = 12, 8192
+    d_src = synth.synth_batch_native(nblocks, nch, ns, first_block=first, device="cuda")
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    d_dst = torch.empty((nblocks, stride), dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(nblocks, dtype=torch.int64, device="cuda")
+    pk.compress_batch(d_src, d_dst, d_sizes, stride)
+    torch.cuda.synchronize()
+    sizes = d_sizes.cpu().numpy()
+    assert (sizes > 0).all() and (sizes <= stride).all()
+    host_src = d_src.cpu().numpy()
+    host_dst = d_dst.cpu().numpy()
+    po = orc.packer("xdelta_hzr", 4, nch, ns, 3)
+    bad = []
+    for b in range(nblocks):
+        want = po.compress(host_src[b])
+        if host_dst[b, : sizes[b]].tobytes() != want:
+            bad.append(b)
+    assert not bad, "streams differ from the oracle at blocks %s" % bad[:10]
+    assert pk.nb == orc.packer_nb(po)
+    out, used = pk.decompress_batch(d_dst, nblocks, stride)
+    torch.cuda.synchronize()
+    assert torch.equal(out, d_src) and torch.equal(used, d_sizes)
+    pk.close()

@@ -111,6 +111,28 @@ def test_dct_large_ns(api, orc, bps, nch, ns, nblocks):
     pk.close()
 
 
+def test_dct_16384_against_the_reference_stream(api, orc, golden):
+    """The FFT path held to the REAL reference (fixture generated from oracle/_ref at ns = 16384, the largest shape the
+    reference runs in seconds): CR / PRDN gate of SURVEY 8d, coefficients equal except truncation-boundary flips of 1."""
+    import cases
+
+    for c in cases.dct_big_cases():
+        g = golden["dct_big"][c["name"]]
+        want = bytes.fromhex(g["stream"])
+        bps, nch, ns = c["bps"], c["nch"], c["ns"]
+        pk = api.new_dct(bps, nch, ns)
+        got = pk.compress(c["data"])
+        assert abs(len(got) / len(want) - 1) <= CR_TOL
+        frac, dmax = _coeff_mismatch(orc, got, want, bps, nch, ns)
+        assert dmax <= 1 and frac <= 2e-3, (frac, dmax)
+        # the GPU inverse on the reference's stream, and on its own
+        for s in (want, got):
+            dec, used = pk.decompress(s)
+            assert used == len(s)
+            assert abs(orc.prdn(c["data"], dec, ns, nch, bps) - g["prdn"]) <= PRDN_TOL
+        pk.close()
+
+
 def test_dct_unsupported_sizes(api):
     with pytest.raises(Exception):
         api.new_dct(4, 1, 8193 + 7)  # > 8192 and not a power of two

@@ -34,3 +34,18 @@ def test_big_handle_refuses_table_paths(orc):
     with pytest.raises(RuntimeError):
         pk.compress(np.zeros(4 * 16384, dtype=np.uint8))
     pk.close()
+
+
+def test_fp64_restatement_equals_reference_at_16384(orc, golden):
+    """ns = 16384: beyond the GPU build's dense-table limit, still within the reference's reach (1 GiB table).  The fixture
+    holds the REAL reference's stream (tests/golden/make_golden.py); the fp64 restatement reproduces it byte for byte."""
+    import cases
+
+    for c in cases.dct_big_cases():
+        g = golden["dct_big"][c["name"]]
+        want = bytes.fromhex(g["stream"])
+        got, _ = orc.dct_big_compress(c["data"], c["bps"], c["nch"], c["ns"])
+        assert got == want
+        dec, used = orc.dct_big_decompress(want, c["bps"], c["nch"], c["ns"])
+        assert used == len(want)
+        assert abs(orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"]) - g["prdn"]) <= PRDN_TOL
