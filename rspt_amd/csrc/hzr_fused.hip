@@ -1,0 +1,827 @@
+// hzr_fused.hip -- the workgroup-per-block hzr encoder as ONE pass over the plane bytes.
+//
+//   k_biglist  the hzr blocks this encoder takes (more than kSmallSegments non-zero 4 KiB segments), in stream order
+//   k_fused    persistent 1024-thread workgroups, one hzr block at a time, the block's 64 KiB held in registers
+//              (four 16-byte granules per lane) from the load to the last bit:
+//                tokenizer + per-wave 261-bin histograms   (hzr_encode.c:133-173)
+//                Huffman tree / Fill test / mode           (:222-305,377-469; build_tree, one wave)
+//                codes into an LDS image of the payload    (:410-457)
+//                CRC-32C, block header, copy-out           (hzr_crc32c.c:77-84, hzr_encode.c:475-481)
+//              The stream offset of a block is the sum of the encoded sizes before it: every block publishes its size as
+//              soon as its tree is known and finds its offset by a decoupled look-back over its predecessors' words
+//              (blocks are claimed in stream order from one counter, so a predecessor is always finished or running).
+//
+// Token attribution (any rule that keeps stream order is the reference's greedy walk, hzr_encode.c:410-457): the tokens
+// of a zero run belong to the run's LAST byte.  A run of length R is floor(R / 16662) capped tokens and one token for the
+// remainder; only backward context (zeros before a granule) and ONE byte of lookahead (is the next byte zero?) are needed.
+//
+// Two row shapes (a row = 1 KiB, one granule per lane), chosen per row by the wave:
+//   dense   the zero flags of byte i of all 64 lanes live in one 64-bit scalar mask per byte position, so run ends, runs of
+//           one and two zeros and dead zero bytes are scalar logic; every byte position is one table lookup per lane.
+//           Runs of three and more zeros (rare here) are handled per lane afterwards.
+//   sparse  per-lane masks; a lane lists its entries (literal with the run in front of it, or a run that ends the
+//           granule) into a per-wave queue, and the wave then takes the queue 64 entries at a time.
+#include "common.hpp"
+
+namespace rspt {
+
+
+// ---------------------------------------------------------------------------
+// k_biglist: ordered compaction of the hzr blocks k_fused takes.  One workgroup; 16 consecutive blocks per thread.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_biglist(const uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, Geom g,
+                                                 uint32_t nhb_total, uint32_t* __restrict__ big_list, WorkQueues* __restrict__ wq) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    const uint32_t per_block = kMaxPlanes * g.nblk;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t chunk = 0; chunk < nhb_total; chunk += 16384u) {
+        const uint32_t first = chunk + tid * 16u;
+        uint32_t mask = 0;  // bit e: block first+e is big
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            const uint32_t hb = first + e;
+            if (hb < nhb_total) {
+                const uint32_t b = hb / per_block, k = (hb - b * per_block) / g.nblk;
+                if (k < nbuse[b] && (uint32_t)__popc(nzflag[hb]) > kSmallSegments) mask |= 1u << e;
+            }
+        }
+        const uint32_t n = (uint32_t)__popc(mask);
+        const uint32_t inc = wave_scan_add(n);
+        if (l == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t pre = s_base, tot = 0;
+        for (uint32_t q = 0; q < 16; ++q) {
+            if (q < w) pre += s_w[q];
+            tot += s_w[q];
+        }
+        uint32_t o = pre + inc - n;
+        uint32_t m = mask;
+        while (m) {
+            const uint32_t e = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            big_list[o++] = first + e;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) wq->n_big = s_base;
+}
+
+// ---------------------------------------------------------------------------
+// LDS of k_fused.  The histogram / tree phase and the payload image never live at the same time.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kQueueEntries = 320;  // entries per wave and row in the sparse-row queue (5 x 64)
+struct FusedP1 {
+    uint32_t whist[kEncWaves][kSymStride];  // tokens whose last byte lies in each wave's 4 KiB segment
+    uint32_t bhist[kSymStride];             // the block's histogram
+    TreeLds tree;
+    uint32_t queue[kEncWaves][kQueueEntries];
+};
+struct FusedLds {
+    uint2 tab[kSymStride];  // {code, length} per lookup index; 261..263 = {0, 0} (a byte that starts no token)
+    uint32_t crc[4][256];   // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
+    uint32_t runcls[kRunClsEntries];
+    uint32_t tdesc[kTdescWords];
+    uint32_t scr[2 * kEncWaves];
+    uint32_t wsum[kEncWaves];
+    uint32_t blk[8];  // mode, payload_len, tree_bits, ntok, fill, -, offset lo, offset hi
+    uint32_t crc_out;
+    uint32_t slot;
+    union {
+        uint32_t stage[kStagePhys];  // X || payload (+ read slack); light blocks queue sparse-row entries in its tail
+        FusedP1 p1;
+    };
+};
+static_assert(sizeof(FusedP1) <= sizeof(uint32_t) * kStagePhys, "phase-1 scratch must fit the image");
+static_assert(sizeof(FusedLds) <= 80 * 1024, "two workgroups per CU");
+static_assert(kTokQueueBase + kEncWaves * kQueueEntries <= kStageWords, "emit-phase queues sit in the image tail");
+__shared__ FusedLds g_f;
+
+// trailing (highest-address) zero bytes of a granule that is not all zero
+__device__ __forceinline__ uint32_t trail_zero_bytes(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return w3 ? ((uint32_t)__clz((int)w3) >> 3) : w2 ? 4u + ((uint32_t)__clz((int)w2) >> 3) : w1 ? 8u + ((uint32_t)__clz((int)w1) >> 3)
+                                                                                             : 12u + ((uint32_t)__clz((int)w0) >> 3);
+}
+__device__ __forceinline__ uint32_t zero_mask16(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
+    return zero_nibble(w0) | (zero_nibble(w1) << 4) | (zero_nibble(w2) << 8) | (zero_nibble(w3) << 12);
+}
+__device__ __forceinline__ bool lane_bit(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// zeros immediately before every lane's granule: the nearest lower lane whose granule is not all zero closes the run
+__device__ __forceinline__ uint32_t zeros_before(bool allz, uint32_t trail, uint32_t zb0) {
+    const uint32_t l = lane_id();
+    const unsigned long long nonall = ~__ballot(allz);
+    const unsigned long long below = nonall & ((1ull << l) - 1ull);
+    const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+    const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
+    return below ? (16u * (l - 1u - p) + tp) : (16u * l + zb0);
+}
+
+// length of the zero run whose last byte is byte i of the granule (lits = its non-zero bytes, zb = zeros before it)
+__device__ __forceinline__ uint32_t run_ending_at(uint32_t i, uint32_t lits, uint32_t zb) {
+    const uint32_t m = lits & ((1u << i) - 1u);
+    return m ? i - (31u - (uint32_t)__clz((int)m)) : i + 1u + zb;
+}
+
+__device__ __forceinline__ void hist_run(uint32_t* h, const uint32_t* runcls, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    if (q) atomicAdd(&h[260], q);
+    if (rem) atomicAdd(&h[runcls[min(rem, kRunClsEntries - 1u)] & 0xFFFu], 1u);
+}
+
+// stream bits of the tokens of a zero run
+__device__ __forceinline__ uint32_t run_bits_tab(const uint2* tab, const uint32_t* runcls, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    uint32_t bits = q ? q * (tab[260].y + 14u) : 0u;
+    if (rem) {
+        const uint32_t e = runcls[min(rem, kRunClsEntries - 1u)];
+        bits += tab[e & 0xFFFu].y + ((e >> 12) & 0xFu);
+    }
+    return bits;
+}
+
+// the remainder token of a run (0 < rem < 16662) as a bit string
+__device__ __forceinline__ void run_token(const uint2* tab, const uint32_t* runcls, uint32_t rem, uint64_t& v, uint32_t& len) {
+    const uint32_t e = runcls[min(rem, kRunClsEntries - 1u)];
+    const uint2 cw = tab[e & 0xFFFu];
+    v = (uint64_t)cw.x | ((uint64_t)(rem - (e >> 16)) << cw.y);
+    len = cw.y + ((e >> 12) & 0xFu);
+}
+
+// OR the tokens of a zero run into the image at bit `pos`; returns the bits written
+__device__ __forceinline__ uint32_t emit_run(uint32_t* stage, const uint2* tab, const uint32_t* runcls, uint32_t pos, uint32_t R) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    uint32_t done = 0;
+    if (q) {
+        const uint2 c = tab[260];
+        const uint64_t v = (uint64_t)c.x | ((uint64_t)(kRunCap - 279u) << c.y);
+        for (uint32_t i = 0; i < q; ++i) {
+            or_token(stage, pos + done, (uint32_t)v, (uint32_t)(v >> 32), c.y + 14u);
+            done += c.y + 14u;
+        }
+    }
+    if (rem) {
+        uint64_t v;
+        uint32_t len;
+        run_token(tab, runcls, rem, v, len);
+        or_token(stage, pos + done, (uint32_t)v, (uint32_t)(v >> 32), len);
+        done += len;
+    }
+    return done;
+}
+
+// what a row needs to know about its surroundings (wave-uniform)
+struct RowCtx {
+    uint32_t zb0;       // zeros immediately before the row's first byte (cut at the block start)
+    uint32_t nz_after;  // 1: the byte behind the row's last valid byte is non-zero, or the block ends there
+    uint32_t valid;     // bytes of this row inside the block (0..1024)
+};
+
+// ===========================================================================
+// dense rows: scalar zero masks per byte position
+// ===========================================================================
+struct DenseMasks {
+    unsigned long long Z[16];
+    unsigned long long c1, c2, cz;
+    __device__ __forceinline__ unsigned long long p1(int i) const { return i >= 1 ? Z[i - 1] : ((Z[15] << 1) | c1); }
+    __device__ __forceinline__ unsigned long long p2(int i) const {
+        return i >= 2 ? Z[i - 2] : i == 1 ? ((Z[15] << 1) | c1) : ((Z[14] << 1) | c2);
+    }
+    __device__ __forceinline__ unsigned long long nx(int i) const { return i <= 14 ? Z[i + 1] : ((Z[0] >> 1) | cz); }
+};
+__device__ __forceinline__ void dense_masks(const uint32_t (&w)[4], const RowCtx& rc, DenseMasks& M) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) M.Z[i] = __ballot(((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) == 0u);
+    M.c1 = rc.zb0 >= 1 ? 1ull : 0ull;
+    M.c2 = rc.zb0 >= 2 ? 1ull : 0ull;
+    M.cz = rc.nz_after ? 0ull : (1ull << 63);
+}
+
+// per-lane view of the same row, for the lanes that hold a run of three or more zeros (or a slow quad)
+struct LaneView {
+    uint32_t zm, lits, zb;
+    uint32_t len1, len2, lng;  // run ends by class (bit i = byte i)
+};
+__device__ __forceinline__ LaneView lane_view(const uint32_t (&w)[4], const RowCtx& rc, const DenseMasks& M) {
+    LaneView v;
+    v.zm = zero_mask16(w[0], w[1], w[2], w[3]);
+    v.lits = ~v.zm & 0xFFFFu;
+    const bool allz = v.zm == 0xFFFFu;
+    const uint32_t trail = allz ? 0u : trail_zero_bytes(w[0], w[1], w[2], w[3]);
+    v.zb = zeros_before(allz, trail, rc.zb0);
+    const uint32_t b1 = lane_bit(M.p1(0)) ? 1u : 0u, b2 = lane_bit(M.p2(0)) ? 1u : 0u, bn = lane_bit(M.nx(15)) ? 1u : 0u;
+    const uint32_t end = v.zm & ~((v.zm >> 1) | (bn << 15));
+    const uint32_t zme = (v.zm << 2) | (b1 << 1) | b2;  // bit i+2 = z(i), bit 1 = z(-1), bit 0 = z(-2)
+    const uint32_t pz1 = zme >> 1, pz2 = zme;           // bit i = z(i-1), z(i-2)
+    v.len1 = end & ~pz1;
+    v.len2 = end & pz1 & ~pz2;
+    v.lng = end & pz1 & pz2;
+    return v;
+}
+
+__device__ __forceinline__ void hist_row_dense(const uint32_t (&w)[4], const RowCtx& rc, uint32_t* h, const uint32_t* runcls) {
+    DenseMasks M;
+    dense_masks(w, rc, M);
+    unsigned long long longany = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const unsigned long long P1 = M.p1(i), P2 = M.p2(i);
+        const unsigned long long End = M.Z[i] & ~M.nx(i);
+        const unsigned long long Len2 = End & P1 & ~P2;
+        const unsigned long long Dead = M.Z[i] & ~(End & ~P1) & ~Len2;  // zero bytes that are neither a run of one nor the end of a run of two
+        uint32_t idx = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+        if (Dead | Len2) {
+            idx = lane_bit(Dead) ? 261u : idx;
+            idx = lane_bit(Len2) ? 256u : idx;
+        }
+        atomicAdd(&h[idx], 1u);
+        longany |= End & P1 & P2;
+    }
+    if (longany) {
+        const LaneView v = lane_view(w, rc, M);
+        uint32_t t = v.lng;
+        while (t) {
+            const uint32_t i = (uint32_t)__builtin_ctz(t);
+            t &= t - 1;
+            hist_run(h, runcls, run_ending_at(i, v.lits, v.zb));
+        }
+    }
+}
+
+// One dense row from lookup to image.  `base` = stream bit at which this row's tokens start.
+__device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const RowCtx& rc, const uint2* tab, const uint32_t* runcls, uint32_t* stage,
+                                               uint32_t& base) {
+    DenseMasks M;
+    dense_masks(w, rc, M);
+    unsigned long long longany = 0;
+    uint32_t qlo[4], qhi[4], qlen[4];
+    uint32_t slow = 0;  // bit q: quad q is emitted token by token
+#pragma unroll
+    for (int h8 = 0; h8 < 16; h8 += 8) {
+        uint2 c[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = h8 + e;
+            const unsigned long long P1 = M.p1(i), P2 = M.p2(i);
+            const unsigned long long End = M.Z[i] & ~M.nx(i);
+            const unsigned long long Len2 = End & P1 & ~P2;
+            const unsigned long long Dead = M.Z[i] & ~(End & ~P1) & ~Len2;
+            uint32_t idx = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
+            if (Dead | Len2) {
+                idx = lane_bit(Dead) ? 261u : idx;
+                idx = lane_bit(Len2) ? 256u : idx;
+            }
+            c[e] = tab[idx];
+            longany |= End & P1 & P2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int qd = (h8 >> 2) + qq;
+            const uint2 c0 = c[4 * qq], c1 = c[4 * qq + 1], c2 = c[4 * qq + 2], c3 = c[4 * qq + 3];
+            const uint32_t s1 = c0.y + c1.y, s2 = c2.y + c3.y;
+            const uint32_t v01 = c0.x | (c1.x << (c0.y & 31u));
+            const uint32_t v23 = c2.x | (c3.x << (c2.y & 31u));
+            const uint64_t V = (uint64_t)v01 | ((uint64_t)v23 << (s1 & 63u));
+            qlo[qd] = (uint32_t)V;
+            qhi[qd] = (uint32_t)(V >> 32);
+            qlen[qd] = s1 + s2;
+            if ((s1 > 32u) | (s2 > 32u)) slow |= 1u << qd;
+        }
+    }
+    LaneView v{};
+    const bool anylong = longany != 0;
+    if (anylong) {  // (wave-uniform) runs of three and more zeros: their bits join the quad's length, the quad goes the slow way
+        v = lane_view(w, rc, M);
+        uint32_t t = v.lng;
+        while (t) {
+            const uint32_t i = (uint32_t)__builtin_ctz(t);
+            t &= t - 1;
+            const uint32_t bits = run_bits_tab(tab, runcls, run_ending_at(i, v.lits, v.zb));
+            const uint32_t qd = i >> 2;
+            qlen[0] += qd == 0 ? bits : 0u;
+            qlen[1] += qd == 1 ? bits : 0u;
+            qlen[2] += qd == 2 ? bits : 0u;
+            qlen[3] += qd == 3 ? bits : 0u;
+            slow |= 1u << qd;
+        }
+    }
+    const uint32_t tot = qlen[0] + qlen[1] + qlen[2] + qlen[3];
+    const uint32_t inc = wave_scan_add(tot);
+    uint32_t pq[4];
+    pq[0] = base + inc - tot;
+    pq[1] = pq[0] + qlen[0];
+    pq[2] = pq[1] + qlen[1];
+    pq[3] = pq[2] + qlen[2];
+    base += read_lane(inc, 63);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+        if (qlen[qd] && !((slow >> qd) & 1u)) or_bits64(stage, pq[qd], qlo[qd], qhi[qd]);
+    if (__ballot(slow != 0)) {
+        if (!anylong) v = lane_view(w, rc, M);
+        const uint32_t qmask = ((slow & 1u) ? 0x000Fu : 0u) | ((slow & 2u) ? 0x00F0u : 0u) | ((slow & 4u) ? 0x0F00u : 0u) | ((slow & 8u) ? 0xF000u : 0u);
+        uint32_t ts = (v.lits | v.len1 | v.len2 | v.lng) & qmask;
+        uint32_t prevq = 4, pp = 0;
+        while (ts) {
+            const uint32_t i = (uint32_t)__builtin_ctz(ts);
+            ts &= ts - 1;
+            const uint32_t qd = i >> 2;
+            if (qd != prevq) pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
+            prevq = qd;
+            if ((v.lng >> i) & 1u) {
+                pp += emit_run(stage, tab, runcls, pp, run_ending_at(i, v.lits, v.zb));
+            } else {
+                const uint32_t idx = ((v.len2 >> i) & 1u) ? 256u : granule_byte_dyn(w[0], w[1], w[2], w[3], i);
+                const uint2 cw = tab[idx];
+                or_token(stage, pp, cw.x, 0u, cw.y);
+                pp += cw.y;
+            }
+        }
+    }
+}
+
+// ===========================================================================
+// sparse rows: per-lane entries.  entry = lit | R << 9: R zeros, then (lit < 256) the literal
+// ===========================================================================
+constexpr uint32_t kNoLit = 0x100u;
+struct SparseLane {
+    uint32_t lits, nv, zb;
+    uint32_t tail;   // 1: the granule ends with a run that ends there
+    uint32_t tailR;  // its length
+    uint32_t nent;
+};
+__device__ __forceinline__ SparseLane sparse_lane(const uint32_t (&w)[4], const RowCtx& rc) {
+    SparseLane s;
+    const uint32_t l = lane_id();
+    const int32_t left = (int32_t)rc.valid - (int32_t)(16u * l);
+    s.nv = left <= 0 ? 0u : left >= 16 ? 16u : (uint32_t)left;
+    const uint32_t vmask = (1u << s.nv) - 1u;
+    const uint32_t zr = zero_mask16(w[0], w[1], w[2], w[3]);
+    const uint32_t zm = zr & vmask;
+    s.lits = ~zr & vmask;
+    const bool allz = s.nv == 16u && zm == 0xFFFFu;
+    const uint32_t trail = (s.nv == 16u && !allz) ? trail_zero_bytes(w[0], w[1], w[2], w[3]) : 0u;  // (a partial granule ends the block)
+    s.zb = zeros_before(allz, trail, rc.zb0);
+    const unsigned long long z0 = __ballot(s.nv > 0u && (zm & 1u));
+    const unsigned long long nextz = (z0 >> 1) | (rc.nz_after ? 0ull : (1ull << 63));
+    const bool nextzero = s.nv == 16u && lane_bit(nextz);
+    const bool lastzero = s.nv > 0u && ((zm >> (s.nv - 1u)) & 1u);
+    s.tail = (lastzero && !nextzero) ? 1u : 0u;
+    s.tailR = s.lits ? (s.nv - 1u - (31u - (uint32_t)__clz((int)s.lits))) : s.nv + s.zb;
+    s.nent = (uint32_t)__popc(s.lits) + s.tail;
+    return s;
+}
+
+// f(R, lit): the lane's entries in stream order
+template <class F>
+__device__ __forceinline__ void lane_entries(const uint32_t (&w)[4], const SparseLane& s, F f) {
+    uint32_t t = s.lits, pe = 0;
+    bool first = true;
+    while (t) {
+        const uint32_t i = (uint32_t)__builtin_ctz(t);
+        t &= t - 1;
+        const uint32_t R = first ? (i ? i + s.zb : 0u) : (i - pe);  // (i == 0: a run that ended with the granule before is counted there)
+        f(R, granule_byte_dyn(w[0], w[1], w[2], w[3], i));
+        pe = i + 1u;
+        first = false;
+    }
+    if (s.tail) f(s.tailR, kNoLit);
+}
+
+// returns false when the row holds nothing; else fills the queue (if the row fits) and returns the entry count in T
+__device__ __forceinline__ bool sparse_queue(const uint32_t (&w)[4], const SparseLane& s, uint32_t* queue, uint32_t& T) {
+    const uint32_t incl = wave_scan_add(s.nent);
+    T = read_lane(incl, 63);
+    if (T == 0) return false;
+    if (queue && T <= kQueueEntries) {
+        uint32_t k = incl - s.nent;
+        lane_entries(w, s, [&](uint32_t R, uint32_t lit) { queue[k++] = lit | (R << 9); });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool row_is_quiet(const uint32_t (&w)[4], const RowCtx& rc) {
+    // nothing but zeros, and the run goes on behind the row: no token ends here
+    return rc.valid == 0u || (rc.valid == 1024u && !rc.nz_after && !__ballot((w[0] | w[1] | w[2] | w[3]) != 0u));
+}
+
+__device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t* h, const uint32_t* runcls, uint32_t* queue) {
+    if (row_is_quiet(w, rc)) return;
+    const SparseLane s = sparse_lane(w, rc);
+    uint32_t T;
+    if (!sparse_queue(w, s, queue, T)) return;
+    if (T <= kQueueEntries) {
+        const uint32_t l = lane_id();
+        for (uint32_t c = 0; c < T; c += 64) {
+            const uint32_t e = c + l < T ? queue[c + l] : kNoLit;
+            const uint32_t R = e >> 9, lit = e & 0x1FFu;
+            if (R) hist_run(h, runcls, R);
+            if (lit < 256u) atomicAdd(&h[lit], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();  // the queue is reused by the next row
+    } else {
+        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+            if (R) hist_run(h, runcls, R);
+            if (lit < 256u) atomicAdd(&h[lit], 1u);
+        });
+    }
+}
+
+__device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, const uint2* tab, const uint32_t* runcls, uint32_t* stage,
+                                                uint32_t& base, uint32_t* queue) {
+    if (row_is_quiet(w, rc)) return;
+    const SparseLane s = sparse_lane(w, rc);
+    uint32_t T;
+    if (!sparse_queue(w, s, queue, T)) return;
+    if (queue && T <= kQueueEntries) {
+        const uint32_t l = lane_id();
+        for (uint32_t c = 0; c < T; c += 64) {
+            const uint32_t e = c + l < T ? queue[c + l] : kNoLit;
+            const uint32_t R = e >> 9, lit = e & 0x1FFu;
+            const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+            const uint32_t rem = R - q * kRunCap;
+            uint64_t rv = 0;
+            uint32_t rl = 0;
+            if (rem) run_token(tab, runcls, rem, rv, rl);
+            const uint2 lc = tab[lit < 256u ? lit : 261u];
+            const uint64_t V = rv | ((uint64_t)lc.x << rl);  // <= 38 + 24 bits
+            const uint32_t vlen = rl + lc.y;
+            const uint32_t caplen = q ? q * (tab[260].y + 14u) : 0u;
+            const uint32_t len = caplen + vlen;
+            const uint32_t inc = wave_scan_add(len);
+            uint32_t pos = base + inc - len;
+            base += read_lane(inc, 63);
+            if (q) pos += emit_run(stage, tab, runcls, pos, q * kRunCap);
+            if (vlen) or_bits64(stage, pos, (uint32_t)V, (uint32_t)(V >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        // no queue (a heavy block's image leaves no room) or a row with too many entries: every lane walks its own, twice
+        uint32_t bits = 0;
+        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+            if (R) bits += run_bits_tab(tab, runcls, R);
+            if (lit < 256u) bits += tab[lit].y;
+        });
+        const uint32_t inc = wave_scan_add(bits);
+        uint32_t pos = base + inc - bits;
+        base += read_lane(inc, 63);
+        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+            if (R) pos += emit_run(stage, tab, runcls, pos, R);
+            if (lit < 256u) {
+                const uint2 cw = tab[lit];
+                or_token(stage, pos, cw.x, 0u, cw.y);
+                pos += cw.y;
+            }
+        });
+    }
+}
+
+// dense or sparse?  (wave-uniform)  Dense needs a whole row; it pays when few granules are all zero.
+__device__ __forceinline__ bool row_is_dense(const uint32_t (&w)[4], const RowCtx& rc) {
+    if (rc.valid != 1024u) return false;
+    return __popcll(__ballot((w[0] | w[1] | w[2] | w[3]) == 0u)) < 16;
+}
+
+// ---------------------------------------------------------------------------
+// stream-offset look-back (one wave): sum of the encoded sizes of the blocks [hb0, hb) of this stream
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t scan_lookback(const uint64_t* __restrict__ state, uint32_t hb, uint32_t hb0, bool& failed) {
+    const uint32_t l = lane_id();
+    uint64_t excl = 0;
+    uint32_t hi = hb;  // predecessors not yet summed: [hb0, hi)
+    failed = false;
+    while (hi > hb0) {
+        const bool in = hi - hb0 > l;  // this lane's predecessor hi - 1 - l exists
+        uint64_t v = kScanPre;         // beyond the stream start: a prefix of 0 ends the walk
+        uint32_t spins = 0;
+        for (;;) {
+            if (in) v = __hip_atomic_load(&state[hi - 1u - l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!__ballot((v >> 62) == 0ull)) break;
+            if (++spins > (1u << 20)) {  // ~0.3 s: a predecessor that never publishes is a bug, not a reason to hang the GPU
+                failed = true;
+                return 0;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        const unsigned long long pre = __ballot((v >> 62) == 2ull);
+        const uint32_t stop = pre ? (uint32_t)__builtin_ctzll(pre) : 64u;  // nearest predecessor that knows its prefix
+        const uint32_t agg = wave_add_u32(l < stop ? (uint32_t)(v & kScanVal) : 0u);  // (sizes are < 2^17: no overflow over 64 lanes)
+        excl += agg;
+        if (pre) {
+            const uint32_t lo = read_lane((uint32_t)v, stop), hi32 = read_lane((uint32_t)(v >> 32), stop);
+            excl += (((uint64_t)hi32 << 32) | lo) & kScanVal;
+            break;
+        }
+        hi -= 64u;
+    }
+    return excl;
+}
+
+// ===========================================================================
+// one hzr block by one workgroup
+// ===========================================================================
+__device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ planes, const Geom& g, const uint32_t* __restrict__ nzflag,
+                                            BlockMeta* __restrict__ meta, uint64_t* __restrict__ scan_state, const CrcConsts* __restrict__ cc,
+                                            uint8_t* __restrict__ dst, uint64_t dst_stride, WorkQueues* __restrict__ wq) {
+    FusedLds& d = g_f;
+    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63u;
+    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    const uint32_t segmask = nzflag[hb];
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+
+    // ---- the block: four granules per lane, straight into registers -------------------------------------------------
+    uint32_t W[4][4];
+    const bool seg_nz = (segmask >> w) & 1u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = w * 4096u + r * 1024u + l * 16u;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (seg_nz && pos < in_size) v = *reinterpret_cast<const uint4*>(in + pos);  // plane rows are padded: a partial granule may over-read
+        W[r][0] = v.x;
+        W[r][1] = v.y;
+        W[r][2] = v.z;
+        W[r][3] = v.w;
+        if (pos + 16u > in_size && pos < in_size) {  // the block's last, partial granule: bytes behind it read as zero
+            const uint32_t nv = in_size - pos;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t lo = q * 4u;
+                W[r][q] = nv >= lo + 4u ? W[r][q] : nv <= lo ? 0u : (W[r][q] & ((1u << ((nv - lo) * 8u)) - 1u));
+            }
+        }
+    }
+    uint32_t* myhist = d.p1.whist[w];
+    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) myhist[i] = 0;
+
+    // ---- zero-run context of the wave's rows --------------------------------------------------------------------------
+    // rows[r]: chain element of row r (all-zero flag | zeros at its end); a row cut by the block end closes every run
+    uint32_t rowel[4], rvalid[4], fbz[4];  // fbz: 1 = the row's first byte is a (valid) zero
+    uint32_t carry = kZIdentity;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t rb = w * 4096u + r * 1024u;
+        rvalid[r] = rb >= in_size ? 0u : min(1024u, in_size - rb);
+        const int32_t left = (int32_t)rvalid[r] - (int32_t)(16u * l);
+        const bool full = left >= 16;
+        const bool allz = full && (W[r][0] | W[r][1] | W[r][2] | W[r][3]) == 0u;
+        const uint32_t trail = (full && !allz) ? trail_zero_bytes(W[r][0], W[r][1], W[r][2], W[r][3]) : 0u;
+        const unsigned long long nonall = ~__ballot(allz);
+        uint32_t el = kZAll | 1024u;
+        if (nonall) {
+            const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
+            el = 16u * (63u - ph) + read_lane(trail, ph);
+        }
+        rowel[r] = el;
+        carry = zcomb(carry, el);
+        fbz[r] = (rvalid[r] > 0u && (read_lane(W[r][0], 0) & 0xFFu) == 0u) ? 1u : 0u;
+    }
+    if (l == 0) {
+        d.scr[w] = carry;
+        d.scr[kEncWaves + w] = fbz[0];
+    }
+    __syncthreads();  // B1 (also: every wave's histogram is zeroed)
+    uint32_t sf = l < (uint32_t)kEncWaves ? d.scr[l] : kZIdentity;
+    sf = row_scan_prefix(sf, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
+    uint32_t pre = w ? read_lane(sf, w - 1u) : kZIdentity;  // everything before this wave
+    const uint32_t next_fbz = w + 1u < (uint32_t)kEncWaves ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d.scr[kEncWaves + w + 1u]) : 0u;
+    RowCtx rc[4];
+    {
+        uint32_t c = pre;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rc[r].zb0 = c & ~kZAll;
+            rc[r].valid = rvalid[r];
+            rc[r].nz_after = r < 3 ? (fbz[r + 1] ? 0u : 1u) : (next_fbz ? 0u : 1u);  // (a row past the block end has fbz = 0: "non-zero")
+            c = zcomb(c, rowel[r]);
+        }
+    }
+
+    // ---- histogram pass ---------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+        if (row_is_dense(W[0], rc[0]))
+            hist_row_dense(W[0], rc[0], myhist, d.runcls);
+        else
+            hist_row_sparse(W[0], rc[0], myhist, d.runcls, d.p1.queue[w]);
+        {  // rotate: the body exists once, the rows pass through W[0]; four turns put everything back
+            uint32_t t0 = W[0][0], t1 = W[0][1], t2 = W[0][2], t3 = W[0][3];
+            const RowCtx tc = rc[0];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                W[q][0] = W[q + 1][0];
+                W[q][1] = W[q + 1][1];
+                W[q][2] = W[q + 1][2];
+                W[q][3] = W[q + 1][3];
+                rc[q] = rc[q + 1];
+            }
+            W[3][0] = t0;
+            W[3][1] = t1;
+            W[3][2] = t2;
+            W[3][3] = t3;
+            rc[3] = tc;
+        }
+    }
+    __syncthreads();  // B2
+    if (tid < (uint32_t)kSymStride) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int wv = 0; wv < kEncWaves; ++wv) t += d.p1.whist[wv][tid];
+        d.p1.bhist[tid] = t;
+    }
+    __syncthreads();  // B3
+
+    // ---- tree (one wave) ------------------------------------------------------------------------------------------------
+    if (w == 0) {
+        const TreeOut r = build_tree(d.p1.tree, d.p1.bhist, in_size, [&](uint32_t sym, uint32_t code, uint32_t len) { d.tab[sym] = make_uint2(code, len); });
+        if (r.mode == kModeHuff)
+            for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) d.tdesc[i] = d.p1.tree.tdesc[i];
+        if (l == 0) {
+            d.blk[0] = r.mode;
+            d.blk[1] = r.payload_len;
+            d.blk[2] = r.tree_bits;
+            d.blk[3] = r.ntok;
+            d.blk[4] = r.fill;
+            // the size is final: let the blocks behind this one find their offsets
+            scan_publish(scan_state, hb, kScanAgg | (7ull + r.payload_len));
+            meta[hb] = BlockMeta{r.mode, r.payload_len, r.tree_bits, r.mode == kModeHuff ? r.ntok : r.fill};
+        }
+    }
+    __syncthreads();  // B4
+    const uint32_t mode = d.blk[0], L = d.blk[1], tree_bits = d.blk[2], ntok = d.blk[3];
+    if (mode == kModeFill) return;  // one distinct value: k_layout writes the 8 bytes (EncodeFill, hzr_encode.c:341-367)
+
+    uint32_t base = 0;
+    if (mode == kModeHuff) {
+        // stream bit at which this wave's tokens start: its histogram x the code lengths, prefix over the waves
+        uint32_t bits = 0;
+        for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * d.p1.tree.key[s];  // (unused symbols: count 0)
+        bits = wave_add_u32(bits);
+        if (l == 0) d.wsum[w] = bits;
+        // clean-block invariant: a light block leaves zeros behind.  Each lane is the only reader of its granules.
+        if (ntok <= kWipeTokens) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (W[r][0] | W[r][1] | W[r][2] | W[r][3]) *reinterpret_cast<uint4*>(in + w * 4096u + r * 1024u + l * 16u) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();  // B5: wsum complete, nobody reads the phase-1 scratch any more
+    if (mode == kModeHuff) {
+        uint32_t ws = l < (uint32_t)kEncWaves ? d.wsum[l] : 0u;
+        ws = row_scan_prefix(ws, 0u, [](uint32_t a, uint32_t c) { return a + c; });
+        base = 32u + tree_bits + (w ? read_lane(ws, w - 1u) : 0u);  // the payload starts at image byte 4
+    }
+    // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
+    {
+        const uint32_t zwords = ((L + 4u) >> 2) + 24u;
+        for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+    }
+    __syncthreads();  // B6
+    if (mode == kModeHuff) {
+        const uint32_t twords = (tree_bits + 31u) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
+        if (tid < twords) atomicOr(&d.stage[1u + tid], d.tdesc[tid]);
+        uint32_t* queue = L < kLightPayload ? d.stage + kTokQueueBase + w * kQueueEntries : nullptr;
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+            if (row_is_dense(W[0], rc[0]))
+                emit_row_dense(W[0], rc[0], d.tab, d.runcls, d.stage, base);
+            else
+                emit_row_sparse(W[0], rc[0], d.tab, d.runcls, d.stage, base, queue);
+        {  // rotate: the body exists once, the rows pass through W[0]; four turns put everything back
+            uint32_t t0 = W[0][0], t1 = W[0][1], t2 = W[0][2], t3 = W[0][3];
+            const RowCtx tc = rc[0];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                W[q][0] = W[q + 1][0];
+                W[q][1] = W[q + 1][1];
+                W[q][2] = W[q + 1][2];
+                W[q][3] = W[q + 1][3];
+                rc[q] = rc[q + 1];
+            }
+            W[3][0] = t0;
+            W[3][1] = t1;
+            W[3][2] = t2;
+            W[3][3] = t3;
+            rc[3] = tc;
+        }
+        }
+    } else {
+        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block, from the registers
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t pos = w * 4096u + r * 1024u + l * 16u;
+            if (pos < in_size) {
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) d.stage[1u + (pos >> 2) + q] = W[r][q];  // (bytes past in_size were masked to zero at the load)
+            }
+        }
+    }
+    if (tid == 0) atomicOr(&d.stage[0], cc->prefix);  // X (word 0 was zeroed above)
+    __syncthreads();  // B7
+
+    // ---- stream offset: wave 0 walks back over the sizes published before this block ------------------------------------
+    if (w == 0) {
+        bool failed;
+        const uint32_t hb0 = hb_index(g, b, 0, 0);
+        const uint64_t excl = scan_lookback(scan_state, hb, hb0, failed);
+        if (l == 0) {
+            const uint64_t off = failed ? ~0ull : 1ull + g.hdr_len + 8ull * (k + 1u) + excl;
+            d.blk[6] = (uint32_t)off;
+            d.blk[7] = (uint32_t)(off >> 32);
+            if (failed)
+                atomicOr(&wq->error, 1u);
+            scan_publish(scan_state, hb, kScanPre | (excl + 7ull + L));  // (after a failure: still a value, so that nobody spins on it)
+        }
+    }
+
+    // ---- CRC-32C: V = X || payload as 4-byte virtual words counted from its END (tools/kernel_model.py:crc_strided) --------
+    {
+        const int32_t Lv = (int32_t)L + 4;
+        const uint32_t nvw = (uint32_t)(Lv + 3) >> 2;
+        const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;
+        auto vword = [&](uint32_t r) -> uint32_t {
+            const int32_t lo = Lv - 4 * (int32_t)(r + 1);
+            const int32_t a = lo >> 2;
+            const uint32_t w_lo = a >= 0 ? d.stage[a] : 0u, w_hi = d.stage[a + 1];
+            return __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)lo & 3u);
+        };
+        uint32_t c = 0;
+        if (tid < nvw) {
+            for (uint32_t kk = K - 1; kk >= 1; --kk) {
+                const uint32_t r = tid + kEncThreads * kk;
+                if (r < nvw) c ^= vword(r);
+                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];
+            }
+            c ^= vword(tid);
+        }
+        if (__ballot(c != 0)) {
+            const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));
+            if (l == 0) d.wsum[w] = gf_shift(cc, 63u - 4u * w, red);
+        } else if (l == 0) {
+            d.wsum[w] = 0;
+        }
+        __syncthreads();  // B8
+        if (tid == 0) {
+            uint32_t t = 0;
+            for (int i = 0; i < kEncWaves; ++i) t ^= d.wsum[i];
+            d.crc_out = ~t;
+        }
+        __syncthreads();  // B9
+    }
+
+    // ---- block header + payload to the stream (hzr_encode.c:475-481) -----------------------------------------------------
+    const uint64_t off = (uint64_t)d.blk[6] | ((uint64_t)d.blk[7] << 32);
+    if (off == ~0ull || off + 7ull + L > dst_stride) return;  // (the stream does not fit: k_layout flags it)
+    uint8_t* o = dst + (size_t)b * dst_stride + off;
+    if (tid == 0) {
+        const uint32_t crc = d.crc_out;
+        o[0] = (uint8_t)(L - 1);
+        o[1] = (uint8_t)((L - 1) >> 8);
+        o[2] = (uint8_t)crc;
+        o[3] = (uint8_t)(crc >> 8);
+        o[4] = (uint8_t)(crc >> 16);
+        o[5] = (uint8_t)(crc >> 24);
+        o[6] = (uint8_t)mode;
+    }
+    uint8_t* po = o + 7;
+    const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
+    const uint32_t nd = (L - head) >> 2;
+    const uint32_t tail = L - head - 4 * nd;
+    if (tid < head) po[tid] = (uint8_t)stage_byte(d.stage, 4 + tid);
+    if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)stage_byte(d.stage, 4 + head + 4 * nd + tid);
+    uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
+    for (uint32_t i = tid; i < nd; i += kEncThreads) pw[i] = __builtin_amdgcn_alignbyte(d.stage[i + 2], d.stage[i + 1], head);
+}
+
+__global__ __launch_bounds__(kEncThreads, 8) void k_fused(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+                                                         BlockMeta* __restrict__ meta, uint64_t* __restrict__ scan_state,
+                                                         const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                                         WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list, uint32_t nhb_total) {
+    (&g_f.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
+    if (threadIdx.x < kRunClsEntries) g_f.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
+    if (threadIdx.x >= 261 && threadIdx.x < (uint32_t)kSymStride) g_f.tab[threadIdx.x] = make_uint2(0u, 0u);
+    const uint32_t n_big = wq->n_big, n_all = n_big + wq->n_big2;
+    // persistent: blocks are claimed in stream order from ONE counter (no static first item: a claimed block must belong to
+    // a running workgroup, or the look-back of a later block could wait for one that has not started)
+    for (;;) {
+        __syncthreads();  // everyone is done with the previous block (and with the slot)
+        if (threadIdx.x == 0) g_f.slot = atomicAdd(&wq->next_big, 1u);
+        __syncthreads();
+        const uint32_t i = g_f.slot;
+        if (i >= n_all) break;
+        // (after the ordered list: the small-class blocks k_tree handed over; their sizes were published by k_tree)
+        const uint32_t hb = i < n_big ? big_list[i] : big_list[nhb_total - 1u - (i - n_big)];
+        fused_block(hb, planes, g, nzflag, meta, scan_state, cc, dst, dst_stride, wq);
+    }
+}
+
+}  // namespace rspt

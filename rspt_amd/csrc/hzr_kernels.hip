@@ -193,6 +193,13 @@ constexpr uint32_t kSmallSegments = 2;    // non-zero 4 KiB segments (each costs
 constexpr uint32_t kSmallTokens = 512;    // tokens
 constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
 
+struct WorkQueues {  // zeroed per call
+    uint32_t n_big, n_small;        // blocks of the fused encoder (k_biglist), of the wave-per-block encoder (k_layout)
+    uint32_t next_big, next_small;  // consumed by k_fused / k_encode_small
+    uint32_t error;                 // a look-back gave up (never in a correct run): every stream of the call is flagged
+    uint32_t n_big2;                // small-class blocks that turned out too big for k_encode_small (k_tree): k_fused takes them last
+};
+
 // A wave whose 4 KiB segment is all zero holds a token only where a zero-run token
 // starts: at the block start (no zeros before) or at a multiple of 16662 inside the
 // run (hzr_encode.c:149).  Wave-uniform, so whole waves skip their token loops.
@@ -508,48 +515,17 @@ __device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
     }
 }
 
-__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, const uint8_t* __restrict__ planes, Geom g,
-                                                         const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
-                                                         uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
-                                                         BlockMeta* __restrict__ meta, const uint32_t* __restrict__ seghist,
-                                                         uint32_t* __restrict__ segbase) {
-    __shared__ TreeLds s_t[kTreeWaves];
-    const uint32_t l = lane_id();
-    const uint32_t wv = threadIdx.x >> 6;
-    // wave -> hzr block, plane-major: all the blocks of plane 0 (the dense, expensive ones) are dispatched first and
-    // next to each other, so they spread over every CU; in (b, k, j) order they recur with a period that the
-    // dispatcher's round-robin maps onto a quarter of the CUs (profiles/r01_notes.md: placement resonance)
-    const uint32_t v = blockIdx.x * kTreeWaves + wv;
-    if (v >= nhb_total) return;
-    const uint32_t per_plane = nhb_total / kMaxPlanes;  // = blocks * nblk
-    const uint32_t k = v / per_plane, rest = v - k * per_plane;
-    const uint32_t b = rest / g.nblk, j = rest - b * g.nblk;
-    const uint32_t hb = hb_index(g, b, k, j);
-    TreeLds& t = s_t[wv];
-    if (k >= nbuse[b]) {
-        if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
-        return;
-    }
-    const uint32_t segmask = nzflag[hb];
-    if (!segmask) {  // all-zero block (flagged by the front end): EncodeFill with value 0
-        if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
-        return;
-    }
-    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    uint32_t* h = t.lhist;
-    const bool own_hist = (uint32_t)__popc(segmask) <= kSmallSegments;
-    if (l == 0) segbase[(size_t)hb * kEncWaves] = 0xFFFFFFFFu;  // "no segment offsets" unless set below
-    if (own_hist) {  // small block: this wave takes the histogram itself
-        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        small_block_hist(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock, in_size, segmask, h);
-    } else {
-        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = hist[(size_t)hb * kSymStride + i];
-    }
-    __threadfence_block();
-    __builtin_amdgcn_wave_barrier();
+struct TreeOut {  // wave-uniform
+    uint32_t mode, payload_len, tree_bits, ntok, fill;
+};
 
+// One wave: token histogram h[0..260] (LDS) of an hzr block of in_size bytes -> Fill test (hzr_encode.c:285-305),
+// Huffman tree with the reference's tie-break (:222-283), code words via put_cw(sym, code, len), the pre-order tree
+// description in t.tdesc (:177-219), stream bits per token of every used symbol in t.key[sym], and the block's mode
+// and exact payload size (:377-469).
+template <class PutCw>
+__device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uint32_t in_size, PutCw put_cw) {
+    const uint32_t l = lane_id();
     // ---- leaves in ascending symbol order (hzr_encode.c:226-234) ----------
     uint32_t cnt[5], idx[5];
     uint32_t base = 0, nonzero_syms = 0, zero_kind = 0, fillval = 0;
@@ -568,11 +544,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         if (nzb) fillval = max(fillval, (uint32_t)(r * 64 + (63 - __builtin_clzll(nzb))));
     }
     const uint32_t S = base;
-    uint32_t* cwo = cw + (size_t)hb * kSymStride;
-    if (zero_kind + nonzero_syms == 1) {  // EncodeFill (hzr_encode.c:341-367)
-        if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, zero_kind ? 0u : fillval};
-        return;
-    }
+    if (zero_kind + nonzero_syms == 1) return TreeOut{kModeFill, 1u, 0u, 0u, zero_kind ? 0u : fillval};  // EncodeFill (:341-367)
 
     // ---- node arrays -------------------------------------------------------
     for (uint32_t i = l; i < 5 * 64; i += 64) t.key[i] = kKeyMax;
@@ -630,7 +602,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
             cur = u & 1023u;
         }
         const uint32_t sym = t.leafsym[i];
-        cwo[sym] = code | (len << 24);
+        put_cw(sym, code, len);
         t.key[sym] = len + run_extra_bits(sym);  // stream bits per token of this symbol (the key slots are free now)
         // description: '1' then the 9-bit symbol, LSB first (hzr_encode.c:184-191)
         const uint32_t v = 1u | (sym << 1);
@@ -643,42 +615,71 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     const uint32_t ntok = wave_add_u32(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4]);
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
-    for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
     const uint32_t total_bits = tree_bits + bits_sum;
     const uint32_t nbytes = (total_bits + 7) >> 3;
     // Huffman iff the payload fits in in_size bytes and is < 65536 (hzr_encode.c:377-382,463-469)
     const bool huff = nbytes <= in_size && nbytes < kHzrBlock;
-    if (l == 0) {
-        if (huff)
-            meta[hb] = BlockMeta{kModeHuff, nbytes, tree_bits, ntok};  // (fill is unused in this mode: it carries the token count)
-        else
-            meta[hb] = BlockMeta{kModeCopy, in_size, 0, 0};
-    }
-    if (!huff || own_hist) return;
+    if (huff) return TreeOut{kModeHuff, nbytes, tree_bits, ntok, 0u};  // (ntok travels in BlockMeta::fill in this mode)
+    return TreeOut{kModeCopy, in_size, 0u, 0u, 0u};
+}
 
-    // ---- stream bit at which the tokens of each 4 KiB segment start (k_hist's per-segment histograms x code lengths) ----
-    // lane l: segment l / 4, quarter l % 4 of its 132 u16 pairs
-    {
-        const uint32_t seg = l >> 2, part = l & 3u;
-        const uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2) + seg * (kSymStride / 2) + part * 33u;
-        uint32_t pr[33];
-#pragma unroll
-        for (int i = 0; i < 33; ++i) pr[i] = sh[i];
-        uint32_t acc = 0;
-#pragma unroll
-        for (int i = 0; i < 33; ++i) {
-            const uint32_t s0 = 2u * (part * 33u + (uint32_t)i);
-            // unused symbols (and the padding past 260) have count 0: whatever their cost slots hold is multiplied away
-            acc += (pr[i] & 0xFFFFu) * t.key[s0];
-            acc += (pr[i] >> 16) * t.key[s0 + 1u];
+// Stream-offset scan shared with the fused encoder (hzr_fused.hip): one word per hzr block, flag in the top two bits.
+constexpr uint64_t kScanAgg = 1ull << 62;  // value = this block's encoded size (7 + payload)
+constexpr uint64_t kScanPre = 2ull << 62;  // value = sum of the encoded sizes of this block and all before it in its stream
+constexpr uint64_t kScanVal = (1ull << 62) - 1ull;
+__device__ __forceinline__ void scan_publish(uint64_t* state, uint32_t hb, uint64_t word) {
+    __hip_atomic_store(&state[hb], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// k_tree: one wave per hzr block.  Takes the blocks the workgroup-per-block encoder does not: planes beyond nb (skip),
+// all-zero blocks (Fill(0)), and the SMALL blocks (<= kSmallSegments non-zero 4 KiB segments), whose histogram it takes
+// itself.  Every block it settles publishes its encoded size for the fused encoder's stream-offset scan.
+__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+                                                         const uint32_t* __restrict__ nzflag, uint32_t nhb_total, uint32_t* __restrict__ cw,
+                                                         uint32_t* __restrict__ tdesc, BlockMeta* __restrict__ meta,
+                                                         uint64_t* __restrict__ scan_state, WorkQueues* __restrict__ wq,
+                                                         uint32_t* __restrict__ big_list) {
+    __shared__ TreeLds s_t[kTreeWaves];
+    const uint32_t l = lane_id();
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t hb = blockIdx.x * kTreeWaves + wv;
+    if (hb >= nhb_total) return;
+    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    TreeLds& t = s_t[wv];
+    if (k >= nbuse[b]) {
+        if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
+        return;
+    }
+    const uint32_t segmask = nzflag[hb];
+    if (!segmask) {  // all-zero block (flagged by the front end): EncodeFill with value 0
+        if (l == 0) {
+            meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
+            scan_publish(scan_state, hb, kScanAgg | 8ull);
         }
-        acc += dpp<0xB1>(0u, acc);  // quad_perm [1,0,3,2]
-        acc += dpp<0x4E>(0u, acc);  // quad_perm [2,3,0,1]: every lane of the quad holds the segment's bits
-        // exclusive prefix over the 16 segments (one value per quad): scan with the quad's bits counted once
-        const uint32_t mine = part == 0 ? acc : 0u;
-        const uint32_t incl = wave_scan_add(mine);
-        if (part == 0) segbase[(size_t)hb * kEncWaves + seg] = 32u + tree_bits + incl - mine;  // the payload starts at image byte 4
+        return;
+    }
+    if ((uint32_t)__popc(segmask) > kSmallSegments) return;  // a big block: the fused encoder takes it from here
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    uint32_t* h = t.lhist;
+    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    small_block_hist(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock, in_size, segmask, h);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    uint32_t* cwo = cw + (size_t)hb * kSymStride;
+    const TreeOut r = build_tree(t, h, in_size, [&](uint32_t sym, uint32_t code, uint32_t len) { cwo[sym] = code | (len << 24); });
+    if (r.mode == kModeHuff) {
+        uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
+        for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
+    }
+    if (l == 0) {
+        meta[hb] = BlockMeta{r.mode, r.payload_len, r.tree_bits, r.mode == kModeHuff ? r.ntok : r.fill};
+        scan_publish(scan_state, hb, kScanAgg | (7ull + r.payload_len));
+        // few non-zero segments, but too many tokens / too long a payload for the wave-per-block encoder (or PlainCopy): the
+        // fused encoder takes it after its own list (which fills big_list from the front; these go in from the back)
+        const bool small_ok = r.mode == kModeHuff && r.payload_len <= kSmallPayload && r.ntok <= kSmallTokens;
+        if (r.mode != kModeFill && !small_ok) big_list[nhb_total - 1u - atomicAdd(&wq->n_big2, 1u)] = hb;
     }
 }
 
@@ -697,17 +698,12 @@ __device__ __forceinline__ void store_le32(uint8_t* p, uint32_t v) {
 // right here; Huffman blocks with few tokens and a small payload go to the `small` queue (one WAVE encodes one such
 // block), everything else to the `big` queue (one 1024-thread workgroup per block).
 
-struct WorkQueues {
-    uint32_t n_big, n_small;      // filled by k_layout
-    uint32_t next_big, next_small;  // consumed by k_encode
-};
 
 __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restrict__ nbuse, const BlockMeta* __restrict__ meta,
                                                const uint8_t* __restrict__ means_hdr, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes, const CrcConsts* __restrict__ cc,
                                                const uint32_t* __restrict__ nzflag, WorkQueues* __restrict__ wq,
-                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list,
-                                               uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
+                                               uint32_t* __restrict__ small_list, uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
     __shared__ uint64_t s_part[256];
     __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
     __shared__ uint32_t s_dirty[kMaxPlanes * 4];  // 128 bits per plane: hzr blocks (j >> dirty_shift) that keep their data
@@ -754,7 +750,7 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
     if (tid == 0) s_plane_end[0] = 0;
     __syncthreads();
     const uint64_t total = head + 8ull * nb + s_plane_end[nb];
-    const bool fits = total <= dst_stride;
+    const bool fits = total <= dst_stride && wq->error == 0u;
     if (tid == 0) sizes[b] = fits ? total : (total | (1ull << 63));
     // the planes written in this call: dirty when a dense block stays behind, or when nothing will be encoded (and wiped) at all
     if (tid < nb * 4) plane_dirty[(size_t)b * kMaxPlanes * 4 + tid] = fits ? s_dirty[tid] : 0xFFFFFFFFu;
@@ -780,9 +776,7 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
         } else if (m.mode == kModeHuff && m.payload_len <= kSmallPayload && m.fill <= kSmallTokens &&
                    __popc(nzflag[hb0 + q]) <= (int)kSmallSegments) {
             small_list[atomicAdd(&wq->n_small, 1u)] = hb0 + q;
-        } else if (m.mode == kModeHuff || m.mode == kModeCopy) {
-            big_list[atomicAdd(&wq->n_big, 1u)] = hb0 + q;
-        }
+        }  // (everything else was encoded by k_fused)
     }
     if (tid == 0) o[0] = (uint8_t)g.method;  // signal_packer_base.cpp:83
     for (uint32_t i = tid; i < g.hdr_len; i += 256) o[1 + i] = means_hdr[(size_t)b * g.hdr_len + i];  // :86-91
@@ -808,7 +802,7 @@ constexpr uint32_t kStagePhys = kStageWords + 2;
 constexpr uint32_t kRunClsEntries = 280;  // lengths 0..278 and ">= 279" (hzr_internal.h:117-121)
 __device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
     const uint32_t sym = run_symbol(z);
-    const uint32_t base = sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : sym == 260 ? 279u : 0u;
+    const uint32_t base = sym == 257 ? 3u : sym == 258 ? 7u : sym == 259 ? 23u : sym == 260 ? 279u : z;  // (runs of 1 and 2: no extra bits, value 0)
     return sym | (run_extra_bits(sym) << 12) | (base << 16);
 }
 
