@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librspt_hip.so")
 STAMP = LIB + ".src-sha"
 SOURCES = ["rspt_hip.hip", "signal_packer_hip.cpp"]
-DEPS = SOURCES + ["common.hpp", "preprocess.hip", "hzr_kernels.hip", "hzr_fused.hip", "transforms.hip", "decode.hip", "filter.hip"]
+DEPS = SOURCES + ["common.hpp", "preprocess.hip", "hzr_kernels.hip", "hzr_rows.hip", "transforms.hip", "decode.hip", "filter.hip"]
 INCLUDES = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("rspt_hip.h", "signal_packer.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 

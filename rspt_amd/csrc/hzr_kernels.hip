@@ -37,144 +37,6 @@ __device__ __forceinline__ uint32_t thread_id() {
     return t;
 }
 
-struct LaneBlock {
-    Granule g[4];
-    uint32_t zb[4];  // zeros immediately before granule r (cut at the block start)
-    uint32_t za[4];  // zeros immediately after granule r (cut at the block end)
-};
-
-// scratch: 2*kEncWaves uint32.  segmask bit w = "the 4 KiB segment of wave w holds a non-zero byte"
-// (front-end non-zero map): a wave whose bit is clear does not read HBM at all.
-__device__ __forceinline__ void load_and_chain(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, LaneBlock& L, uint32_t* scratch) {
-    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
-    const bool seg_nz = (segmask >> w) & 1u;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t pos = w * 4096 + r * 1024 + l * 16;
-        Granule& g = L.g[r];
-        g.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g.nv && seg_nz) v = *reinterpret_cast<const uint4*>(in + pos);  // plane rows are padded: a partial granule may over-read, masked below
-        g.w[0] = v.x;
-        g.w[1] = v.y;
-        g.w[2] = v.z;
-        g.w[3] = v.w;
-        granule_finish(g);
-    }
-    // Zero-run chaining with one ballot + one shuffle per row and direction: the
-    // nearest granule that is not all-zero closes the run (tools/kernel_model.py:granule_scan).
-    const unsigned long long lt = (1ull << l) - 1ull;                       // lanes below
-    const unsigned long long gt = l == 63 ? 0ull : ~((2ull << l) - 1ull);  // lanes above
-    // forward (zeros before): rows in order, carry = everything before the row
-    uint32_t carry = kZIdentity;
-    uint32_t fwd_incl[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const Granule& g = L.g[r];
-        const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
-        const uint32_t trail = granule_trail_elem(g) & ~kZAll;
-        const unsigned long long nonall = ~__ballot(allz);
-        uint32_t rows;
-        if (nonall == ~0ull) {
-            // dense row (no granule is all zero): the run before a lane ends in the lane below -- one DPP shift
-            // instead of the mask search and the bpermute
-            const uint32_t tp = dpp<0x138>(0u, trail);  // wave_shr:1
-            fwd_incl[r] = l ? tp : zcomb(carry, kZAll);
-            rows = read_lane(trail, 63);
-        } else {
-            const unsigned long long below = nonall & lt;
-            const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-            const uint32_t tp = (uint32_t)__shfl((int)trail, (int)p, 64);
-            fwd_incl[r] = below ? (16u * (l - 1u - p) + tp) : zcomb(carry, kZAll | (16u * l));
-            rows = kZAll | 1024u;
-            if (nonall) {
-                const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
-                rows = 16u * (63u - ph) + read_lane(trail, ph);  // ph comes from a ballot: wave-uniform
-            }
-        }
-        carry = zcomb(carry, rows);
-    }
-    const uint32_t wave_fwd = carry;
-    // backward (zeros after): rows in reverse
-    carry = kZIdentity;
-    uint32_t bwd_incl[4];
-#pragma unroll
-    for (int r = 3; r >= 0; --r) {
-        const Granule& g = L.g[r];
-        const bool allz = g.nv == 16 && g.zm == 0xFFFFu;
-        const uint32_t lead = granule_lead_elem(g) & ~kZAll;
-        const unsigned long long nonall = ~__ballot(allz);
-        uint32_t rows;
-        if (nonall == ~0ull) {
-            const uint32_t lq = dpp<0x130>(0u, lead);  // wave_shl:1
-            bwd_incl[r] = l != 63u ? lq : zcomb(carry, kZAll);
-            rows = read_lane(lead, 0);
-        } else {
-            const unsigned long long above = nonall & gt;
-            const uint32_t q = above ? (uint32_t)__builtin_ctzll(above) : 63u;
-            const uint32_t lq = (uint32_t)__shfl((int)lead, (int)q, 64);
-            bwd_incl[r] = above ? (16u * (q - l - 1u) + lq) : zcomb(carry, kZAll | (16u * (63u - l)));
-            rows = kZAll | 1024u;
-            if (nonall) {
-                const uint32_t ql = (uint32_t)__builtin_ctzll(nonall);
-                rows = 16u * ql + read_lane(lead, ql);
-            }
-        }
-        carry = zcomb(carry, rows);
-    }
-    const uint32_t wave_bwd = carry;
-    if (l == 0) {
-        scratch[w] = wave_fwd;
-        scratch[kEncWaves + w] = wave_bwd;
-    }
-    __syncthreads();
-    // fold the 16 wave summaries: lane i < 16 takes wave i's, 4-step scans, then pick this wave's neighbours
-    uint32_t sf = l < (uint32_t)kEncWaves ? scratch[l] : kZIdentity;
-    uint32_t sb = l < (uint32_t)kEncWaves ? scratch[kEncWaves + l] : kZIdentity;
-    static_assert(kEncWaves == 16, "the wave summaries fill exactly one DPP row");
-    sf = row_scan_prefix(sf, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
-    sb = row_scan_suffix(sb, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
-    uint32_t pre = read_lane(sf, w ? w - 1 : 0);  // everything before this wave
-    if (w == 0) pre = kZIdentity;
-    uint32_t post = read_lane(sb, w + 1 < (uint32_t)kEncWaves ? w + 1 : w);  // everything after it
-    if (w + 1 == (uint32_t)kEncWaves) post = kZIdentity;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        L.zb[r] = zcomb(pre, fwd_incl[r]) & ~kZAll;
-        L.za[r] = zcomb(post, bwd_incl[r]) & ~kZAll;
-    }
-    __syncthreads();  // scratch may be reused by the caller
-}
-
-// The same LaneBlock from memory: the granule words plus the (zb | za << 16) words k_hist stored for this
-// hzr block (`zbza` = [16 waves][4 rows][64 lanes]).  No ballots, shuffles or barriers.
-__device__ __forceinline__ void load_with_chain(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask,
-                                                const uint32_t* __restrict__ zbza, LaneBlock& L) {
-    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
-    const bool seg_nz = (segmask >> w) & 1u;
-    uint32_t zz[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) zz[r] = zbza[w * 256 + r * 64 + l];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const uint32_t pos = w * 4096 + r * 1024 + l * 16;
-        Granule& g = L.g[r];
-        g.nv = pos < in_size ? min(16u, in_size - pos) : 0u;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g.nv && seg_nz) v = *reinterpret_cast<const uint4*>(in + pos);
-        g.w[0] = v.x;
-        g.w[1] = v.y;
-        g.w[2] = v.z;
-        g.w[3] = v.w;
-        granule_finish(g);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        L.zb[r] = zz[r] & 0xFFFFu;
-        L.za[r] = zz[r] >> 16;
-    }
-}
-
 // byte i (dynamic) of a granule held in four registers
 __device__ __forceinline__ uint32_t granule_byte_dyn(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
     const uint32_t lo = (i & 8u) ? w2 : w0, hi = (i & 8u) ? w3 : w1;
@@ -193,106 +55,10 @@ constexpr uint32_t kSmallSegments = 2;    // non-zero 4 KiB segments (each costs
 constexpr uint32_t kSmallTokens = 512;    // tokens
 constexpr uint32_t kSmallPayload = 3072;  // bytes; a wave's LDS slot holds X + payload + read slack
 
-struct WorkQueues {  // zeroed per call
-    uint32_t n_big, n_small;        // blocks of the fused encoder (k_biglist), of the wave-per-block encoder (k_layout)
-    uint32_t next_big, next_small;  // consumed by k_fused / k_encode_small
-    uint32_t error;                 // a look-back gave up (never in a correct run): every stream of the call is flagged
-    uint32_t n_big2;                // small-class blocks that turned out too big for k_encode_small (k_tree): k_fused takes them last
+struct WorkQueues {
+    uint32_t n_big, n_small;        // filled by k_layout
+    uint32_t next_big, next_small;  // consumed by k_encode / k_encode_small
 };
-
-// A wave whose 4 KiB segment is all zero holds a token only where a zero-run token
-// starts: at the block start (no zeros before) or at a multiple of 16662 inside the
-// run (hzr_encode.c:149).  Wave-uniform, so whole waves skip their token loops.
-__device__ __forceinline__ bool wave_may_have_tokens(uint32_t segmask, const LaneBlock& L) {
-    const uint32_t w = thread_id() >> 6;
-    if ((segmask >> w) & 1u) return true;
-    const uint32_t zb0 = read_lane(L.zb[0], 0);  // zeros before the wave's first byte
-    const uint32_t q = (zb0 >= kRunCap) + (zb0 >= 2 * kRunCap) + (zb0 >= 3 * kRunCap);
-    const uint32_t r = zb0 - q * kRunCap;
-    const uint32_t icap = r ? kRunCap - r : 0u;  // first byte of the segment at which a token starts
-    return icap < 4096u;
-}
-
-// ===========================================================================
-// k_hist
-// ===========================================================================
-// literals at static byte positions (predicated LDS atomics), then the few run
-// tokens by iterating over the `starts` mask.  The callers walk a lane's four
-// granules with a rolled loop that rotates them through one register set, so the
-// body exists once (instruction-cache footprint) and still uses ds_ instructions.
-struct GranuleRegs {  // packed to keep four of them live at the 64-VGPR budget
-    uint32_t w0, w1, w2, w3;
-    uint32_t nvzm;  // zm | nv << 16
-    uint32_t zbza;  // zb | za << 16   (both <= 65520)
-    __device__ __forceinline__ uint32_t nv() const { return nvzm >> 16; }
-    __device__ __forceinline__ uint32_t zm() const { return nvzm & 0xFFFFu; }
-    __device__ __forceinline__ uint32_t zb() const { return zbza & 0xFFFFu; }
-    __device__ __forceinline__ uint32_t za() const { return zbza >> 16; }
-};
-__device__ __forceinline__ GranuleRegs granule_regs(const LaneBlock& L, int r) {
-    return GranuleRegs{L.g[r].w[0], L.g[r].w[1], L.g[r].w[2], L.g[r].w[3], L.g[r].zm | (L.g[r].nv << 16), L.zb[r] | (L.za[r] << 16)};
-}
-// CONST: some lane of the wave holds a granule of sixteen equal non-zero bytes in this block (decided once per block)
-template <bool CONST>
-__device__ __forceinline__ void hist_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
-                                          uint32_t za, uint32_t* s_hist) {
-    GranuleMasks m = granule_masks(zm, nv, zb, za);
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    // A granule of sixteen equal non-zero bytes (the sign bytes of a raw plane, a flat signal): sixteen adds to one bin,
-    // from every lane of the wave at once, would serialise 1024-fold.  Such lanes add 16 once, and the lanes that share the
-    // first such lane's value add through one lane.
-    const bool uni = CONST && nv == 16 && zm == 0 && w0 == w1 && w1 == w2 && w2 == w3 && w0 == (w0 & 0xFFu) * 0x01010101u;
-    const unsigned long long um = CONST ? __ballot(uni) : 0ull;
-    if (um) {
-        const uint32_t lead = (uint32_t)__builtin_ctzll(um);
-        const uint32_t v = w0 & 0xFFu;
-        const uint32_t vlead = read_lane(v, lead);
-        const unsigned long long same = __ballot(uni && v == vlead);
-        if (uni) {
-            if (v != vlead)
-                atomicAdd(&s_hist[v], 16u);
-            else if (lane_id() == lead)
-                atomicAdd(&s_hist[v], 16u * (uint32_t)__popcll(same));
-            m.single = 0;  // (m.runs is empty: no zero byte)
-        }
-    }
-    // tokens without extra bits: literals, lone zeros (symbol 0 = byte value 0), two zeros (symbol 256).  Three
-    // wave-uniform shapes of the row:
-    if (uni) {
-        // nothing left
-    } else if (!__ballot(__popc(m.single) > 4)) {
-        // sparse: a few tokens per lane -- walk them (16 predicated adds would mostly add nothing)
-        uint32_t t = m.single;
-        while (t) {
-            const uint32_t i = (uint32_t)__builtin_ctz(t);
-            t &= t - 1;
-            atomicAdd(&s_hist[granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8)], 1u);
-        }
-    } else if (!__ballot(__popc(zm & ~m.single) > 2)) {
-        // dense and clean (hardly any zero byte that starts no token): every byte adds its token bit to the bin of its
-        // value, unpredicated; the few two-zero tokens are moved from bin 0 to bin 256 afterwards.  (Not for rows with
-        // many dead zeros: same-address LDS atomics serialise even when they add 0.)
-#pragma unroll
-        for (uint32_t i = 0; i < 16; ++i) atomicAdd(&s_hist[(w[i >> 2] >> ((i & 3) * 8)) & 0xFFu], (m.single >> i) & 1u);
-        if (m.two) {
-            const uint32_t n2 = (uint32_t)__popc(m.two);
-            atomicAdd(&s_hist[0], 0u - n2);
-            atomicAdd(&s_hist[256], n2);
-        }
-    } else {
-#pragma unroll
-        for (uint32_t i = 0; i < 16; ++i) {
-            const uint32_t x = ((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) | (((m.two >> i) & 1u) << 8);
-            if ((m.single >> i) & 1u) atomicAdd(&s_hist[x], 1u);
-        }
-    }
-    uint32_t st = m.runs;
-    while (st) {
-        const uint32_t i = (uint32_t)__builtin_ctz(st);
-        st &= st - 1;
-        atomicAdd(&s_hist[run_symbol(run_token_length(zm, nv, za, i))], 1u);
-    }
-}
 
 // Work distribution for k_hist / k_encode.  The hardware places workgroup i on XCD i % 8 and,
 // inside the XCD, walks the CUs round-robin; a grid in which heavy (plane 0) and light
@@ -314,85 +80,7 @@ __device__ __forceinline__ bool next_work(uint32_t* counter, uint32_t total, con
     return true;
 }
 
-// Every wave counts the tokens that START in its own 4 KiB segment into its own LDS histogram.  Two results:
-//   hist     [hb][264] u32     the block's histogram (sum of the 16), input of k_tree
-//   seghist  [hb][16][264] u16 the per-segment histograms: with the code lengths they give k_tree the stream bit
-//                              at which each segment's tokens start, so k_encode needs no bit-count pass and no
-//                              cross-wave prefix of its own (a 4 KiB segment holds <= 4096 tokens: u16 is enough)
-constexpr uint32_t kSegHistStride = kEncWaves * kSymStride;  // u16 elements per hzr block
-
-__global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
-                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ zbza, uint32_t* __restrict__ counter,
-                                                     uint32_t total) {
-    __shared__ uint32_t s_hist[kEncWaves][kSymStride];
-    __shared__ uint32_t s_scr[2 * kEncWaves];
-    __shared__ uint32_t s_slot;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&s_hist[0][0])[i] = 0;
-    WorkItem wi;
-    for (uint32_t pass = 0; next_work(counter, total, g, &s_slot, wi, pass); ++pass) {
-        const uint32_t tid = thread_id();
-        const uint32_t j = wi.j, k = wi.k, b = wi.b;
-        const uint32_t hb = hb_index(g, b, k, j);
-        const uint32_t nbu = nbuse[b];
-        const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
-        if (k >= nbu) continue;
-        if ((uint32_t)__popc(segmask) <= kSmallSegments) continue;  // all zero (k_tree: Fill(0)) or small (k_tree takes the histogram itself)
-        const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-        const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-        LaneBlock L;
-        load_and_chain(in, in_size, segmask, L, s_scr);  // (its barriers also order the zeroing below against this block's adds)
-        {
-            // the zero-run context of every granule, for k_encode (which then needs no chaining of its own)
-            uint32_t* zo = zbza + (size_t)hb * kHzrBlock / 16 + (tid >> 6) * 256 + (tid & 63);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) zo[r * 64] = L.zb[r] | (L.za[r] << 16);
-        }
-        if (wave_may_have_tokens(segmask, L)) {
-            uint32_t* myhist = s_hist[tid >> 6];
-            GranuleRegs q0 = granule_regs(L, 0), q1 = granule_regs(L, 1), q2 = granule_regs(L, 2), q3 = granule_regs(L, 3);
-            // constant granules (sign bytes of a raw plane, a flat signal) need the aggregating variant; a dense xdelta plane
-            // never has one, and pays for one test per block instead of one per row
-            bool cst = false;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const Granule& gg = L.g[r];
-                cst |= gg.zm == 0 && gg.w[0] == gg.w[1] && gg.w[2] == gg.w[3] && gg.w[0] == gg.w[2] && gg.w[0] == __builtin_amdgcn_perm(gg.w[0], gg.w[0], 0u);
-            }
-            if (__ballot(cst)) {
-#pragma unroll 1
-                for (int r = 0; r < 4; ++r) {
-                    hist_granule<true>(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
-                    q0 = q1;
-                    q1 = q2;
-                    q2 = q3;
-                }
-            } else {
-#pragma unroll 1
-                for (int r = 0; r < 4; ++r) {
-                    hist_granule<false>(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), myhist);
-                    q0 = q1;
-                    q1 = q2;
-                    q2 = q3;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < (uint32_t)kSymStride) {
-            uint32_t t = 0;
-#pragma unroll
-            for (int wv = 0; wv < kEncWaves; ++wv) t += s_hist[wv][tid];
-            hist[(size_t)hb * kSymStride + tid] = t;
-        }
-        uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2);
-        for (uint32_t d = tid; d < kSegHistStride / 2; d += kEncThreads) {
-            const uint32_t lo = (&s_hist[0][0])[2 * d], hi = (&s_hist[0][0])[2 * d + 1];
-            sh[d] = lo | (hi << 16);
-        }
-        __syncthreads();  // everyone has read the histograms
-        for (uint32_t i = tid; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&s_hist[0][0])[i] = 0;
-    }
-}
+constexpr uint32_t kSegHistStride = kEncWaves * kSymStride;  // u16 elements per hzr block (hzr_rows.hip: k_hist)
 
 // ===========================================================================
 // k_tree: one wave per hzr block, 4 waves per workgroup
@@ -623,28 +311,26 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
     return TreeOut{kModeCopy, in_size, 0u, 0u, 0u};
 }
 
-// Stream-offset scan shared with the fused encoder (hzr_fused.hip): one word per hzr block, flag in the top two bits.
-constexpr uint64_t kScanAgg = 1ull << 62;  // value = this block's encoded size (7 + payload)
-constexpr uint64_t kScanPre = 2ull << 62;  // value = sum of the encoded sizes of this block and all before it in its stream
-constexpr uint64_t kScanVal = (1ull << 62) - 1ull;
-__device__ __forceinline__ void scan_publish(uint64_t* state, uint32_t hb, uint64_t word) {
-    __hip_atomic_store(&state[hb], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// k_tree: one wave per hzr block.  Takes the blocks the workgroup-per-block encoder does not: planes beyond nb (skip),
-// all-zero blocks (Fill(0)), and the SMALL blocks (<= kSmallSegments non-zero 4 KiB segments), whose histogram it takes
-// itself.  Every block it settles publishes its encoded size for the fused encoder's stream-offset scan.
-__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                         const uint32_t* __restrict__ nzflag, uint32_t nhb_total, uint32_t* __restrict__ cw,
-                                                         uint32_t* __restrict__ tdesc, BlockMeta* __restrict__ meta,
-                                                         uint64_t* __restrict__ scan_state, WorkQueues* __restrict__ wq,
-                                                         uint32_t* __restrict__ big_list) {
+// k_tree: one wave per hzr block, 4 waves per workgroup.  Small blocks (<= kSmallSegments non-zero 4 KiB segments) take their
+// own histogram here; for the others k_hist left the block histogram and the per-segment histograms, which -- times the
+// code lengths -- give the stream bit at which each 4 KiB segment's tokens start (k_encode then needs no bit-count pass).
+__global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __restrict__ hist, const uint8_t* __restrict__ planes, Geom g,
+                                                         const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
+                                                         uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
+                                                         BlockMeta* __restrict__ meta, const uint32_t* __restrict__ seghist,
+                                                         uint32_t* __restrict__ segbase) {
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
-    const uint32_t hb = blockIdx.x * kTreeWaves + wv;
-    if (hb >= nhb_total) return;
-    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    // wave -> hzr block, plane-major: all the blocks of plane 0 (the dense, expensive ones) are dispatched first and
+    // next to each other, so they spread over every CU; in (b, k, j) order they recur with a period that the
+    // dispatcher's round-robin maps onto a quarter of the CUs (profiles/r01_notes.md: placement resonance)
+    const uint32_t v = blockIdx.x * kTreeWaves + wv;
+    if (v >= nhb_total) return;
+    const uint32_t per_plane = nhb_total / kMaxPlanes;  // = blocks * nblk
+    const uint32_t k = v / per_plane, rest = v - k * per_plane;
+    const uint32_t b = rest / g.nblk, j = rest - b * g.nblk;
+    const uint32_t hb = hb_index(g, b, k, j);
     TreeLds& t = s_t[wv];
     if (k >= nbuse[b]) {
         if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
@@ -652,34 +338,57 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint8_t* __restr
     }
     const uint32_t segmask = nzflag[hb];
     if (!segmask) {  // all-zero block (flagged by the front end): EncodeFill with value 0
-        if (l == 0) {
-            meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
-            scan_publish(scan_state, hb, kScanAgg | 8ull);
-        }
+        if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
         return;
     }
-    if ((uint32_t)__popc(segmask) > kSmallSegments) return;  // a big block: the fused encoder takes it from here
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     uint32_t* h = t.lhist;
-    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-    small_block_hist(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock, in_size, segmask, h);
+    const bool own_hist = (uint32_t)__popc(segmask) <= kSmallSegments;
+    if (l == 0) segbase[(size_t)hb * kEncWaves] = 0xFFFFFFFFu;  // "no segment offsets" unless set below
+    if (own_hist) {  // small block: this wave takes the histogram itself
+        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        small_block_hist(planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock, in_size, segmask, h);
+    } else {
+        for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) h[i] = hist[(size_t)hb * kSymStride + i];
+    }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
     uint32_t* cwo = cw + (size_t)hb * kSymStride;
     const TreeOut r = build_tree(t, h, in_size, [&](uint32_t sym, uint32_t code, uint32_t len) { cwo[sym] = code | (len << 24); });
-    if (r.mode == kModeHuff) {
-        uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
-        for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
-    }
-    if (l == 0) {
-        meta[hb] = BlockMeta{r.mode, r.payload_len, r.tree_bits, r.mode == kModeHuff ? r.ntok : r.fill};
-        scan_publish(scan_state, hb, kScanAgg | (7ull + r.payload_len));
-        // few non-zero segments, but too many tokens / too long a payload for the wave-per-block encoder (or PlainCopy): the
-        // fused encoder takes it after its own list (which fills big_list from the front; these go in from the back)
-        const bool small_ok = r.mode == kModeHuff && r.payload_len <= kSmallPayload && r.ntok <= kSmallTokens;
-        if (r.mode != kModeFill && !small_ok) big_list[nhb_total - 1u - atomicAdd(&wq->n_big2, 1u)] = hb;
+    if (l == 0) meta[hb] = BlockMeta{r.mode, r.payload_len, r.tree_bits, r.mode == kModeHuff ? r.ntok : r.fill};
+    if (r.mode != kModeHuff) return;
+    uint32_t* tdo = tdesc + (size_t)hb * kTdescWords;
+    for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) tdo[i] = t.tdesc[i];
+    if (own_hist) return;
+    // (bins 261..263 of k_hist's histograms count the zero bytes that end no token: they cost nothing)
+    if (l < 3u) t.key[(uint32_t)kNumSym + l] = 0u;
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- stream bit at which the tokens of each 4 KiB segment start (k_hist's per-segment histograms x code lengths) ----
+    // lane l: segment l / 4, quarter l % 4 of its 132 u16 pairs
+    {
+        const uint32_t seg = l >> 2, part = l & 3u;
+        const uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2) + seg * (kSymStride / 2) + part * 33u;
+        uint32_t pr[33];
+#pragma unroll
+        for (int i = 0; i < 33; ++i) pr[i] = sh[i];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 33; ++i) {
+            const uint32_t s0 = 2u * (part * 33u + (uint32_t)i);
+            // unused symbols have count 0: whatever their cost slots hold is multiplied away
+            acc += (pr[i] & 0xFFFFu) * t.key[s0];
+            acc += (pr[i] >> 16) * t.key[s0 + 1u];
+        }
+        acc += dpp<0xB1>(0u, acc);  // quad_perm [1,0,3,2]
+        acc += dpp<0x4E>(0u, acc);  // quad_perm [2,3,0,1]: every lane of the quad holds the segment's bits
+        // exclusive prefix over the 16 segments (one value per quad): scan with the quad's bits counted once
+        const uint32_t mine = part == 0 ? acc : 0u;
+        const uint32_t incl = wave_scan_add(mine);
+        if (part == 0) segbase[(size_t)hb * kEncWaves + seg] = 32u + r.tree_bits + incl - mine;  // the payload starts at image byte 4
     }
 }
 
@@ -703,7 +412,8 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
                                                const uint8_t* __restrict__ means_hdr, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes, const CrcConsts* __restrict__ cc,
                                                const uint32_t* __restrict__ nzflag, WorkQueues* __restrict__ wq,
-                                               uint32_t* __restrict__ small_list, uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
+                                               uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list,
+                                               uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
     __shared__ uint64_t s_part[256];
     __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
     __shared__ uint32_t s_dirty[kMaxPlanes * 4];  // 128 bits per plane: hzr blocks (j >> dirty_shift) that keep their data
@@ -750,7 +460,7 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
     if (tid == 0) s_plane_end[0] = 0;
     __syncthreads();
     const uint64_t total = head + 8ull * nb + s_plane_end[nb];
-    const bool fits = total <= dst_stride && wq->error == 0u;
+    const bool fits = total <= dst_stride;
     if (tid == 0) sizes[b] = fits ? total : (total | (1ull << 63));
     // the planes written in this call: dirty when a dense block stays behind, or when nothing will be encoded (and wiped) at all
     if (tid < nb * 4) plane_dirty[(size_t)b * kMaxPlanes * 4 + tid] = fits ? s_dirty[tid] : 0xFFFFFFFFu;
@@ -776,7 +486,9 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
         } else if (m.mode == kModeHuff && m.payload_len <= kSmallPayload && m.fill <= kSmallTokens &&
                    __popc(nzflag[hb0 + q]) <= (int)kSmallSegments) {
             small_list[atomicAdd(&wq->n_small, 1u)] = hb0 + q;
-        }  // (everything else was encoded by k_fused)
+        } else if (m.mode == kModeHuff || m.mode == kModeCopy) {
+            big_list[atomicAdd(&wq->n_big, 1u)] = hb0 + q;
+        }
     }
     if (tid == 0) o[0] = (uint8_t)g.method;  // signal_packer_base.cpp:83
     for (uint32_t i = tid; i < g.hdr_len; i += 256) o[1 + i] = means_hdr[(size_t)b * g.hdr_len + i];  // :86-91
@@ -806,42 +518,6 @@ __device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
     return sym | (run_extra_bits(sym) << 12) | (base << 16);
 }
 
-struct EncLds {
-    uint32_t cw[kSymStride];  // first: the lookups address it with an immediate offset (16 bits)
-    uint32_t crc[4][256];  // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
-    uint32_t scr[2 * kEncWaves];
-    uint32_t wsum[kEncWaves];
-    uint32_t crc_out;
-    uint32_t runcls[kRunClsEntries];  // zero-run length -> symbol | extra bits << 12 | first length of the class << 16
-    uint32_t stage[kStagePhys];
-};
-
-// pass 1: number of stream bits of the tokens that start in this granule
-__device__ __forceinline__ uint32_t bits_granule(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb,
-                                              uint32_t za, const uint32_t* s_cw) {
-    const GranuleMasks m = granule_masks(zm, nv, zb, za);
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    uint32_t nb = 0;
-    // two batches of 8 independent LDS reads each (a single wait per batch instead of one per byte)
-#pragma unroll
-    for (uint32_t h = 0; h < 16; h += 8) {
-        uint32_t c[8];
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) c[i] = s_cw[((w[(h + i) >> 2] >> (((h + i) & 3) * 8)) & 0xFFu) | (((m.two >> (h + i)) & 1u) << 8)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) nb += ((m.single >> (h + i)) & 1u) ? (c[i] >> 24) : 0u;
-    }
-    uint32_t st = m.runs;
-    while (st) {
-        const uint32_t i = (uint32_t)__builtin_ctz(st);
-        st &= st - 1;
-        const uint32_t sym = run_symbol(run_token_length(zm, nv, za, i));
-        nb += (s_cw[sym] >> 24) + run_extra_bits(sym);
-    }
-    return nb;
-}
-
 // OR up to 64 bits (hi:lo) into the image at bit `pos`: three words, unconditionally (zeros are harmless and
 // with 64 lanes some lane needs each of them anyway)
 __device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi) {
@@ -850,25 +526,6 @@ __device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_
     atomicOr(&stage[word], (uint32_t)sv);
     atomicOr(&stage[(word + 1)], (uint32_t)(sv >> 32));
     atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
-}
-
-// The token that starts at byte i of a granule as one bit string: code, then the run's extra bits
-// (hzr_encode.c:422-447).  <= 24 + 14 bits.
-__device__ __forceinline__ void token_at(uint32_t i, const GranuleMasks& m, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t zm,
-                                         uint32_t nv, uint32_t za, const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t& lo, uint32_t& hi,
-                                         uint32_t& len) {
-    const bool is_run = (m.runs >> i) & 1u;
-    const uint32_t z = run_token_length(zm, nv, za, i);
-    const uint32_t e = s_runcls[min(z, kRunClsEntries - 1u)];
-    const uint32_t lit = granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8);
-    const uint32_t cr = s_cw[is_run ? (e & 0xFFFu) : lit];
-    const uint32_t cl = cr >> 24;
-    const uint32_t eb = is_run ? ((e >> 12) & 0xFu) : 0u;
-    const uint32_t xv = is_run ? z - (e >> 16) : 0u;
-    const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)xv << cl);
-    lo = (uint32_t)v;
-    hi = (uint32_t)(v >> 32);
-    len = cl + eb;
 }
 
 // OR one token (<= 38 bits) into the image at bit `pos`
@@ -880,364 +537,11 @@ __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t
     if (sh + len > 64) atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
 }
 
-// One row (a granule per lane, 1 KiB per wave) from lookup to image in a single pass (hzr_encode.c:410-457).
-// `base` = stream bit at which this row's tokens start (k_tree's segment offset plus the rows before); a wave
-// scan of the lanes' bit totals places every lane.  Two wave-uniform shapes:
-//   sparse  no lane holds more than kRowSlots tokens: the tokens are taken one per lane and step, kept in
-//           registers across the scan, and OR-ed into the image
-//   dense   the codes of four adjacent tokens without extra bits (literals, 1- and 2-zero runs) are joined into
-//           one <= 64-bit string per quad of bytes and OR-ed with three LDS atomics; a quad that holds a run token
-//           with extra bits, or a pair of codes longer than 32 bits (both rare in dense planes), is counted
-//           here and emitted token by token afterwards.
-constexpr int kRowSlots = 8;
-constexpr uint32_t kTokQueue = 256;          // tokens per wave and row in the queue of a light block
-constexpr uint32_t kLightPayload = 16384;    // bytes: below it the image words from kTokQueueBase on are free
+constexpr uint32_t kLightPayload = 16384;    // bytes: below it the image words from kTokQueueBase on are free (sparse-row queues)
 constexpr uint32_t kTokQueueBase = 9000;     // stage word (> (16384 + 4) / 4 + 24)
-
-__device__ __forceinline__ void emit_row(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t nv, uint32_t zm, uint32_t zb, uint32_t za,
-                                         const uint32_t* s_cw, const uint32_t* s_runcls, uint32_t* stage, uint32_t& base, uint32_t* tokq) {
-    const GranuleMasks m = granule_masks(zm, nv, zb, za);
-    const uint32_t tokmask = m.single | m.runs;
-    if (!__ballot(tokmask != 0)) return;  // no token starts in this row
-
-    if (tokq) {
-        // Light block (the image beyond its short payload serves as a token queue): a sparse row's tokens sit unevenly
-        // on the lanes (1.4 per lane on average, 6..8 on the fullest), so the lanes only QUEUE them, in stream order,
-        // and the wave then encodes the queue 64 tokens at a time, one token per lane.
-        const uint32_t n = (uint32_t)__popc(tokmask);
-        const uint32_t incl = wave_scan_add(n);
-        const uint32_t T = read_lane(incl, 63);
-        if (T <= kTokQueue) {
-            uint32_t k = incl - n, t = tokmask;
-            while (t) {
-                const uint32_t i = (uint32_t)__builtin_ctz(t);
-                t &= t - 1;
-                const uint32_t z = run_token_length(zm, nv, za, i);
-                const uint32_t lit = granule_byte_dyn(w0, w1, w2, w3, i) | (((m.two >> i) & 1u) << 8);
-                tokq[k++] = ((m.runs >> i) & 1u) ? (0x80000000u | z) : lit;  // run: its length; else the lookup index
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint32_t l = lane_id();
-            for (uint32_t c = 0; c < T; c += 64) {
-                const bool valid = c + l < T;
-                const uint32_t dsc = valid ? tokq[c + l] : 0u;
-                const bool is_run = dsc >> 31;
-                const uint32_t z = dsc & 0x7FFFFFFFu;
-                const uint32_t e = s_runcls[min(z, kRunClsEntries - 1u)];
-                const uint32_t cr = s_cw[is_run ? (e & 0xFFFu) : (dsc & 0x1FFu)];
-                const uint32_t cl = cr >> 24;
-                const uint32_t xv = is_run ? z - (e >> 16) : 0u;
-                const uint64_t v = (uint64_t)(cr & 0x00FFFFFFu) | ((uint64_t)xv << cl);
-                const uint32_t len = valid ? cl + (is_run ? ((e >> 12) & 0xFu) : 0u) : 0u;
-                const uint32_t inc = wave_scan_add(len);
-                const uint32_t pos = base + inc - len;
-                base += read_lane(inc, 63);
-                if (len) or_token(stage, pos, (uint32_t)v, (uint32_t)(v >> 32), len);
-            }
-            __builtin_amdgcn_wave_barrier();  // the queue is reused by the next row
-            return;
-        }
-    }
-
-    if (!__ballot(__popc(tokmask) > kRowSlots)) {
-        uint32_t tlo[kRowSlots], thi[kRowSlots], tlen[kRowSlots];
-        uint32_t t = tokmask, tot = 0;
-#pragma unroll
-        for (int sl = 0; sl < kRowSlots; ++sl) {
-            tlo[sl] = thi[sl] = tlen[sl] = 0;
-            if (__ballot(t != 0)) {
-                if (t) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(t);
-                    t &= t - 1;
-                    token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, s_runcls, tlo[sl], thi[sl], tlen[sl]);
-                    tot += tlen[sl];
-                }
-            }
-        }
-        const uint32_t inc = wave_scan_add(tot);
-        uint32_t pos = base + inc - tot;
-        base += read_lane(inc, 63);
-#pragma unroll
-        for (int sl = 0; sl < kRowSlots; ++sl) {
-            if (tlen[sl]) or_token(stage, pos, tlo[sl], thi[sl], tlen[sl]);
-            pos += tlen[sl];
-        }
-        return;
-    }
-
-    const uint32_t w[4] = {w0, w1, w2, w3};
-    uint32_t qlo[4], qhi[4], qlen[4];
-    uint32_t slow = 0;
-#pragma unroll
-    for (uint32_t h = 0; h < 16; h += 8) {
-        uint32_t c[8];
-#pragma unroll
-        for (uint32_t i = 0; i < 8; ++i) c[i] = s_cw[((w[(h + i) >> 2] >> (((h + i) & 3) * 8)) & 0xFFu) | (((m.two >> (h + i)) & 1u) << 8)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (uint32_t qq = 0; qq < 2; ++qq) {
-            const uint32_t qd = (h >> 2) + qq, p = 4 * qd;
-            uint32_t cc[4];
-#pragma unroll
-            for (uint32_t i = 0; i < 4; ++i)  // keep the word only where a token without extra bits starts (bit -> all-ones mask)
-                cc[i] = c[4 * qq + i] & (uint32_t)__builtin_amdgcn_sbfe((int)m.single, p + i, 1);
-            const uint32_t l0 = cc[0] >> 24, l1 = cc[1] >> 24, l2 = cc[2] >> 24, l3 = cc[3] >> 24;
-            const uint32_t s1 = l0 + l1, s2 = l2 + l3;
-            const uint32_t v01 = (cc[0] & 0x00FFFFFFu) | ((cc[1] & 0x00FFFFFFu) << l0);
-            const uint32_t v23 = (cc[2] & 0x00FFFFFFu) | ((cc[3] & 0x00FFFFFFu) << l2);
-            const uint64_t V = (uint64_t)v01 | ((uint64_t)v23 << s1);
-            qlo[qd] = (uint32_t)V;
-            qhi[qd] = (uint32_t)(V >> 32);
-            qlen[qd] = s1 + s2;
-            const uint32_t r4 = (m.runs >> p) & 0xFu;
-            if (r4 | (uint32_t)(s1 > 32) | (uint32_t)(s2 > 32)) {
-                slow |= 0xFu << p;  // the quad's four bytes
-                uint32_t st = r4 << p;
-                while (st) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(st);
-                    st &= st - 1;
-                    const uint32_t sym = run_symbol(run_token_length(zm, nv, za, i));
-                    qlen[qd] += (s_cw[sym] >> 24) + run_extra_bits(sym);
-                }
-            }
-        }
-    }
-    const uint32_t tot = qlen[0] + qlen[1] + qlen[2] + qlen[3];
-    const uint32_t inc = wave_scan_add(tot);
-    uint32_t pq[4];
-    pq[0] = base + inc - tot;
-    pq[1] = pq[0] + qlen[0];
-    pq[2] = pq[1] + qlen[1];
-    pq[3] = pq[2] + qlen[2];
-    base += read_lane(inc, 63);
-#pragma unroll
-    for (uint32_t qd = 0; qd < 4; ++qd)
-        if (qlen[qd] && !((slow >> (4 * qd)) & 1u)) or_bits64(stage, pq[qd], qlo[qd], qhi[qd]);
-    uint32_t ts = tokmask & slow;  // the tokens of the slow quads, one by one
-    uint32_t prevq = 4, pp = 0;
-    while (ts) {
-        const uint32_t i = (uint32_t)__builtin_ctz(ts);
-        ts &= ts - 1;
-        const uint32_t qd = i >> 2;
-        if (qd != prevq) pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
-        prevq = qd;
-        uint32_t lo, hi, len;
-        token_at(i, m, w0, w1, w2, w3, zm, nv, za, s_cw, s_runcls, lo, hi, len);
-        or_token(stage, pp, lo, hi, len);
-        pp += len;
-    }
-}
 
 // byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
 __device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }
-
-// `ablate` is a timing-only diagnostic (RSPT_ABLATE env var, 0 in normal operation): bit 0 skips the
-// emit pass, bit 1 the CRC, bit 2 the bit-count pass, bit 3 the copy-out.  Outputs are wrong when set.
-// The workgroup-per-block encoder's LDS lives at namespace scope so that encode_block can be a
-// real (not inlined) function and still address it with ds_ instructions: inlined into the
-// persistent loop it spilled ~55 registers per lane at the 64-VGPR budget of two workgroups per CU.
-__shared__ EncLds g_enc;
-
-template <bool DIAG>
-__device__ __forceinline__ void encode_block(uint32_t b, uint32_t k, uint32_t j, uint8_t* __restrict__ planes, const Geom& g,
-                                             const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
-                                             const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
-                                             const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
-                                             uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate_arg,
-                                             unsigned long long* __restrict__ stamps, const uint32_t* __restrict__ segbase,
-                                             const uint32_t* __restrict__ zbza) {
-    EncLds& d = g_enc;
-    const uint32_t ablate = DIAG ? ablate_arg : 0u;  // the production instantiation carries no diagnostic code
-    // diagnostic (ablate bit 7): lane 0 of every wave of 512 hzr blocks (window ablate>>16) stores s_memtime at section seams
-#define RSPT_STAMP(i)                                                                                      \
-    do {                                                                                                   \
-        const uint32_t hb_ = hb_index(g, b, k, j) - (ablate >> 16) * 512u;                \
-        if ((ablate & 128u) && (threadIdx.x & 63u) == 0 && hb_ < 512u)                                                 \
-            stamps[(hb_ * 16u + (threadIdx.x >> 6)) * 8u + (i)] = __builtin_amdgcn_s_memtime();                        \
-    } while (0)
-    const uint32_t hb = hb_index(g, b, k, j);
-    // three independent loads in one round trip (their addresses depend on the block index only)
-    const BlockMeta m = meta[hb];
-    const uint64_t off = out_off[hb];
-    const uint32_t segmask = nzflag[hb];
-    // diagnostic (ablate bit 8): wall-clock (100 MHz) start/end of every workgroup, for a concurrency census
-    if ((ablate & 256u) && threadIdx.x == 0 && hb < 16384u) stamps[65536u + 2u * hb] = __builtin_amdgcn_s_memrealtime();
-    if (m.mode == kModeSkip || (ablate & 16u)) return;  // plane not used by this block (k >= nb)
-    if ((ablate & 4096u) && m.payload_len < 256u) return;   // timing probe: small blocks cost nothing
-    if ((ablate & 8192u) && m.payload_len >= 256u) return;  // timing probe: large blocks cost nothing
-    if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
-    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63;
-    uint8_t* o = dst + (size_t)b * dst_stride + off;
-
-    if (ablate & 64u) {  // occupancy census: every non-fill workgroup idles ~100 us (s_memrealtime ticks at 100 MHz)
-        if (m.mode != kModeFill) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < 10000ull) __builtin_amdgcn_s_sleep(32);
-        }
-        return;
-    }
-    if (m.mode == kModeFill) {  // EncodeFill (hzr_encode.c:341-367): [00 00][crc32c(value)][02][value]
-        if (tid == 0) {
-            uint32_t c = 0xFFFFFFFFu ^ m.fill;
-            c = ~((c >> 8) ^ cc->table[0][c & 0xFFu]);
-            o[0] = 0;
-            o[1] = 0;
-            o[2] = (uint8_t)c;
-            o[3] = (uint8_t)(c >> 8);
-            o[4] = (uint8_t)(c >> 16);
-            o[5] = (uint8_t)(c >> 24);
-            o[6] = (uint8_t)kModeFill;
-            o[7] = (uint8_t)m.fill;
-        }
-        return;
-    }
-
-    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-    const uint32_t L = m.payload_len;
-    RSPT_STAMP(0);
-
-    if (m.mode == kModeHuff) {
-        // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
-        const uint32_t zwords = (((L + 4) >> 2) + 24);
-        for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
-        if (tid < kSymStride) d.cw[tid] = cw[(size_t)hb * kSymStride + tid];
-        LaneBlock B;
-        const uint32_t first_base = segbase[(size_t)hb * kEncWaves];  // 0xFFFFFFFF: no offsets from k_tree (its own-histogram blocks)
-        uint32_t base = segbase[(size_t)hb * kEncWaves + w];           // stream bit at which this wave's tokens start
-        if (first_base == 0xFFFFFFFFu) {
-            load_and_chain(in, in_size, segmask, B, d.scr);  // barriers inside publish cw and the zeroed image
-        } else {
-            load_with_chain(in, in_size, segmask, zbza + (size_t)hb * kHzrBlock / 16, B);  // k_hist went through this block
-            __syncthreads();  // cw and the zeroed image are in place
-        }
-        if (block_is_wiped(m)) {
-            // clean-block invariant: a light block leaves zeros behind.  Each lane was the only reader of its granules.
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const Granule& gr = B.g[r];
-                if (gr.nv && (gr.w[0] | gr.w[1] | gr.w[2] | gr.w[3])) *reinterpret_cast<uint4*>(in + w * 4096 + r * 1024 + l * 16) = make_uint4(0, 0, 0, 0);
-            }
-        }
-        if (ablate & 32u) return;
-        RSPT_STAMP(1);
-        const uint32_t twords = (m.tree_bits + 31) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
-        if (tid < twords) atomicOr(&d.stage[(1 + tid)], tdesc[(size_t)hb * kTdescWords + tid]);
-        const bool active = wave_may_have_tokens(segmask, B);  // wave-uniform
-        GranuleRegs q0 = granule_regs(B, 0), q1 = granule_regs(B, 1), q2 = granule_regs(B, 2), q3 = granule_regs(B, 3);
-        if (first_base == 0xFFFFFFFFu) {
-            // the block's histogram was taken by k_tree in one piece: count this wave's bits here and take the prefix
-            // over the waves (blocks with at most kSmallSegments non-zero segments that were too big for k_encode_small)
-            uint32_t wbits = 0;
-#pragma unroll 1
-            for (int r = 0; r < 4 && active; ++r) {  // rolled: granules rotate through fixed registers
-                wbits += bits_granule(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw);
-                const GranuleRegs t = q0;
-                q0 = q1;
-                q1 = q2;
-                q2 = q3;
-                q3 = t;
-            }
-            wbits = wave_add_u32(wbits);
-            if (l == 0) d.wsum[w] = wbits;
-            __syncthreads();
-            base = 32u + m.tree_bits;  // the payload starts at logical byte 4
-            for (uint32_t i = 0; i < w; ++i) base += d.wsum[i];
-        }
-        RSPT_STAMP(2);
-        RSPT_STAMP(3);
-        uint32_t* tokq = L < kLightPayload ? d.stage + kTokQueueBase + w * kTokQueue : nullptr;
-        // (diagnostic bits 18 / 19: no row emission for heavy / light blocks, to split the instruction count between them)
-        const bool skip_rows = (ablate & 1u) || ((ablate & (1u << 18)) && m.payload_len >= 16384u) || ((ablate & (1u << 19)) && m.payload_len < 16384u);
-#pragma unroll 1
-        for (int r = 0; r < 4 && active && !skip_rows; ++r) {
-            emit_row(q0.w0, q0.w1, q0.w2, q0.w3, q0.nv(), q0.zm(), q0.zb(), q0.za(), d.cw, d.runcls, d.stage, base, tokq);
-            q0 = q1;
-            q1 = q2;
-            q2 = q3;
-        }
-    } else {
-        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
-        for (uint32_t gi = tid; gi < kStageWords / 4 - 1; gi += kEncThreads) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (gi * 16 < in_size) v = *reinterpret_cast<const uint4*>(in + (size_t)gi * 16);
-            d.stage[(1 + gi * 4)] = v.x;
-            d.stage[(2 + gi * 4)] = v.y;
-            d.stage[(3 + gi * 4)] = v.z;
-            d.stage[(4 + gi * 4)] = v.w;
-        }
-    }
-    if (tid == 0) d.stage[0] = cc->prefix;  // X (after this thread's own zeroing of word 0)
-    RSPT_STAMP(4);
-    __syncthreads();
-    RSPT_STAMP(5);
-
-    // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0) as 4-byte virtual words counted from its END;
-    //      lane tid owns the words tid, tid + 1024, ... (consecutive lanes read consecutive LDS words), Horner over its
-    //      words with x^(8*4096) per step, then x^(8*4*(tid+1)) to the end of V; crc = ~raw(V) -------------------------
-    {
-        const int32_t Lv = (int32_t)L + 4;
-        const uint32_t nvw = (uint32_t)(Lv + 3) >> 2;
-        const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;  // steps of the fullest lane (block-uniform)
-        auto vword = [&](uint32_t r) -> uint32_t {  // bytes [Lv - 4(r+1), Lv - 4r) of V; bytes in front of V are zero
-            const int32_t lo = Lv - 4 * (int32_t)(r + 1);
-            const int32_t a = lo >> 2;  // arithmetic: floor
-            const uint32_t w_lo = a >= 0 ? d.stage[a] : 0u, w_hi = d.stage[a + 1];
-            return __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)lo & 3u);
-        };
-        uint32_t c = 0;
-        if (tid < nvw && !(ablate & 2u)) {
-            for (uint32_t k = K - 1; k >= 1; --k) {
-                const uint32_t r = tid + kEncThreads * k;
-                if (r < nvw) c ^= vword(r);
-                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];  // * x^(8*4096)
-            }
-            c ^= vword(tid);
-        }
-        if (__ballot(c != 0)) {  // waves without data skip the shifts
-            const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));  // every lane to the end of the wave's 64 words
-            if (l == 0) d.wsum[w] = gf_shift(cc, 63u - 4u * w, red);  // x^(8*256*w): the wave's group to the end of V
-        } else if (l == 0) {
-            d.wsum[w] = 0;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t t = 0;
-            for (int i = 0; i < kEncWaves; ++i) t ^= d.wsum[i];
-            d.crc_out = ~t;
-        }
-        __syncthreads();
-    }
-
-    RSPT_STAMP(6);
-    // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
-    if (tid == 0) {
-        const uint32_t crc = d.crc_out;
-        o[0] = (uint8_t)(L - 1);
-        o[1] = (uint8_t)((L - 1) >> 8);
-        o[2] = (uint8_t)crc;
-        o[3] = (uint8_t)(crc >> 8);
-        o[4] = (uint8_t)(crc >> 16);
-        o[5] = (uint8_t)(crc >> 24);
-        o[6] = (uint8_t)m.mode;
-    }
-    uint8_t* po = o + 7;
-    const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
-    const uint32_t nd = (L - head) >> 2;
-    const uint32_t tail = L - head - 4 * nd;
-    if (tid < head) po[tid] = (uint8_t)stage_byte(d.stage, 4 + tid);
-    if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)stage_byte(d.stage, 4 + head + 4 * nd + tid);
-    uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
-    if (ablate & 8u) return;
-    for (uint32_t i = tid; i < nd; i += kEncThreads) {
-        // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
-        pw[i] = __builtin_amdgcn_alignbyte(d.stage[(i + 2)], d.stage[(i + 1)], head);
-    }
-    RSPT_STAMP(7);
-    if ((ablate & 256u) && threadIdx.x == 0 && hb < 16384u) stamps[65536u + 2u * hb + 1u] = __builtin_amdgcn_s_memrealtime();
-#undef RSPT_STAMP
-}
 
 // ---------------------------------------------------------------------------------------------
 // Small blocks: one WAVE encodes one hzr block, 16 blocks per workgroup pass, no workgroup barrier.
@@ -1471,32 +775,6 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
     const uint8_t* img8 = reinterpret_cast<const uint8_t*>(img) + 4;
     for (uint32_t i = l; i < L; i += 64) o[7 + i] = img8[i];
     __builtin_amdgcn_wave_barrier();  // the slot is reused by this wave's next block
-}
-
-template <bool DIAG>
-__global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
-                                                          const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
-                                                          const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
-                                                          const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                                          uint32_t ablate, unsigned long long* __restrict__ stamps, WorkQueues* __restrict__ wq,
-                                                          const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ segbase,
-                                                          const uint32_t* __restrict__ zbza) {
-    __shared__ uint32_t s_slot;
-    (&g_enc.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
-    if (threadIdx.x < kRunClsEntries) g_enc.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
-    const uint32_t n_big = wq->n_big;
-    // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
-    // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
-    for (uint32_t pass = 0;; ++pass) {
-        __syncthreads();  // everyone is done with the previous block (and with s_slot)
-        if (threadIdx.x == 0) s_slot = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(&wq->next_big, 1u);
-        __syncthreads();
-        const uint32_t i = s_slot;
-        if (i >= n_big) break;
-        const uint32_t hb = big_list[i];
-        const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
-        encode_block<DIAG>(b, k, j, planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, ablate, stamps, segbase, zbza);
-    }
 }
 
 // small blocks: 4 waves per workgroup, each wave pulls blocks on its own (no workgroup barrier after the table load)

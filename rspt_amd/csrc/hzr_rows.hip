@@ -1,19 +1,16 @@
-// hzr_fused.hip -- the workgroup-per-block hzr encoder as ONE pass over the plane bytes.
+// hzr_rows.hip -- the workgroup-per-block half of the hzr encoder: tokenizer + histogram (k_hist) and code emission
+// (k_encode) for the blocks that are not "small" (hzr_kernels.hip: k_tree / k_encode_small take those).
 //
-//   k_biglist  the hzr blocks this encoder takes (more than kSmallSegments non-zero 4 KiB segments), in stream order
-//   k_fused    persistent 1024-thread workgroups, one hzr block at a time, the block's 64 KiB held in registers
-//              (four 16-byte granules per lane) from the load to the last bit:
-//                tokenizer + per-wave 261-bin histograms   (hzr_encode.c:133-173)
-//                Huffman tree / Fill test / mode           (:222-305,377-469; build_tree, one wave)
-//                codes into an LDS image of the payload    (:410-457)
-//                CRC-32C, block header, copy-out           (hzr_crc32c.c:77-84, hzr_encode.c:475-481)
-//              The stream offset of a block is the sum of the encoded sizes before it: every block publishes its size as
-//              soon as its tree is known and finds its offset by a decoupled look-back over its predecessors' words
-//              (blocks are claimed in stream order from one counter, so a predecessor is always finished or running).
+//   k_hist     persistent 1024-thread workgroups, one hzr block at a time (four 16-byte granules per lane): zero-run
+//              tokenizer (hzr_encode.c:133-173), per-wave 261-bin histograms in LDS -> the block's histogram and the
+//              per-4-KiB-segment histograms (k_tree turns those into the stream bit at which each wave's tokens start)
+//   k_encode   the same block again: codes into an LDS image of the payload (:410-457), CRC-32C (hzr_crc32c.c:77-84),
+//              block header (:475-481), coalesced copy-out to the offset k_layout computed
 //
 // Token attribution (any rule that keeps stream order is the reference's greedy walk, hzr_encode.c:410-457): the tokens
 // of a zero run belong to the run's LAST byte.  A run of length R is floor(R / 16662) capped tokens and one token for the
-// remainder; only backward context (zeros before a granule) and ONE byte of lookahead (is the next byte zero?) are needed.
+// remainder; only backward context (zeros before a granule) and ONE byte of lookahead (is the next byte zero?) are needed,
+// so the chain over the workgroup runs in one direction and nothing about it has to travel from k_hist to k_encode.
 //
 // Two row shapes (a row = 1 KiB, one granule per lane), chosen per row by the wave:
 //   dense   the zero flags of byte i of all 64 lanes live in one 64-bit scalar mask per byte position, so run ends, runs of
@@ -25,81 +22,8 @@
 
 namespace rspt {
 
-
-// ---------------------------------------------------------------------------
-// k_biglist: ordered compaction of the hzr blocks k_fused takes.  One workgroup; 16 consecutive blocks per thread.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_biglist(const uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, Geom g,
-                                                 uint32_t nhb_total, uint32_t* __restrict__ big_list, WorkQueues* __restrict__ wq) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_base;
-    const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
-    const uint32_t per_block = kMaxPlanes * g.nblk;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (uint32_t chunk = 0; chunk < nhb_total; chunk += 16384u) {
-        const uint32_t first = chunk + tid * 16u;
-        uint32_t mask = 0;  // bit e: block first+e is big
-#pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) {
-            const uint32_t hb = first + e;
-            if (hb < nhb_total) {
-                const uint32_t b = hb / per_block, k = (hb - b * per_block) / g.nblk;
-                if (k < nbuse[b] && (uint32_t)__popc(nzflag[hb]) > kSmallSegments) mask |= 1u << e;
-            }
-        }
-        const uint32_t n = (uint32_t)__popc(mask);
-        const uint32_t inc = wave_scan_add(n);
-        if (l == 63) s_w[w] = inc;
-        __syncthreads();
-        uint32_t pre = s_base, tot = 0;
-        for (uint32_t q = 0; q < 16; ++q) {
-            if (q < w) pre += s_w[q];
-            tot += s_w[q];
-        }
-        uint32_t o = pre + inc - n;
-        uint32_t m = mask;
-        while (m) {
-            const uint32_t e = (uint32_t)__builtin_ctz(m);
-            m &= m - 1;
-            big_list[o++] = first + e;
-        }
-        __syncthreads();
-        if (tid == 0) s_base += tot;
-        __syncthreads();
-    }
-    if (tid == 0) wq->n_big = s_base;
-}
-
-// ---------------------------------------------------------------------------
-// LDS of k_fused.  The histogram / tree phase and the payload image never live at the same time.
-// ---------------------------------------------------------------------------
 constexpr uint32_t kQueueEntries = 320;  // entries per wave and row in the sparse-row queue (5 x 64)
-struct FusedP1 {
-    uint32_t whist[kEncWaves][kSymStride];  // tokens whose last byte lies in each wave's 4 KiB segment
-    uint32_t bhist[kSymStride];             // the block's histogram
-    TreeLds tree;
-    uint32_t queue[kEncWaves][kQueueEntries];
-};
-struct FusedLds {
-    uint2 tab[kSymStride];  // {code, length} per lookup index; 261..263 = {0, 0} (a byte that starts no token)
-    uint32_t crc[4][256];   // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
-    uint32_t runcls[kRunClsEntries];
-    uint32_t tdesc[kTdescWords];
-    uint32_t scr[2 * kEncWaves];
-    uint32_t wsum[kEncWaves];
-    uint32_t blk[8];  // mode, payload_len, tree_bits, ntok, fill, -, offset lo, offset hi
-    uint32_t crc_out;
-    uint32_t slot;
-    union {
-        uint32_t stage[kStagePhys];  // X || payload (+ read slack); light blocks queue sparse-row entries in its tail
-        FusedP1 p1;
-    };
-};
-static_assert(sizeof(FusedP1) <= sizeof(uint32_t) * kStagePhys, "phase-1 scratch must fit the image");
-static_assert(sizeof(FusedLds) <= 80 * 1024, "two workgroups per CU");
 static_assert(kTokQueueBase + kEncWaves * kQueueEntries <= kStageWords, "emit-phase queues sit in the image tail");
-__shared__ FusedLds g_f;
 
 // trailing (highest-address) zero bytes of a granule that is not all zero
 __device__ __forceinline__ uint32_t trail_zero_bytes(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
@@ -491,57 +415,15 @@ __device__ __forceinline__ bool row_is_dense(const uint32_t (&w)[4], const RowCt
     return __popcll(__ballot((w[0] | w[1] | w[2] | w[3]) == 0u)) < 16;
 }
 
-// ---------------------------------------------------------------------------
-// stream-offset look-back (one wave): sum of the encoded sizes of the blocks [hb0, hb) of this stream
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t scan_lookback(const uint64_t* __restrict__ state, uint32_t hb, uint32_t hb0, bool& failed) {
-    const uint32_t l = lane_id();
-    uint64_t excl = 0;
-    uint32_t hi = hb;  // predecessors not yet summed: [hb0, hi)
-    failed = false;
-    while (hi > hb0) {
-        const bool in = hi - hb0 > l;  // this lane's predecessor hi - 1 - l exists
-        uint64_t v = kScanPre;         // beyond the stream start: a prefix of 0 ends the walk
-        uint32_t spins = 0;
-        for (;;) {
-            if (in) v = __hip_atomic_load(&state[hi - 1u - l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (!__ballot((v >> 62) == 0ull)) break;
-            if (++spins > (1u << 20)) {  // ~0.3 s: a predecessor that never publishes is a bug, not a reason to hang the GPU
-                failed = true;
-                return 0;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        const unsigned long long pre = __ballot((v >> 62) == 2ull);
-        const uint32_t stop = pre ? (uint32_t)__builtin_ctzll(pre) : 64u;  // nearest predecessor that knows its prefix
-        const uint32_t agg = wave_add_u32(l < stop ? (uint32_t)(v & kScanVal) : 0u);  // (sizes are < 2^17: no overflow over 64 lanes)
-        excl += agg;
-        if (pre) {
-            const uint32_t lo = read_lane((uint32_t)v, stop), hi32 = read_lane((uint32_t)(v >> 32), stop);
-            excl += (((uint64_t)hi32 << 32) | lo) & kScanVal;
-            break;
-        }
-        hi -= 64u;
-    }
-    return excl;
-}
 
 // ===========================================================================
-// one hzr block by one workgroup
+// the block in registers: four granules per lane, and what every row has to know about its surroundings
 // ===========================================================================
-__device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ planes, const Geom& g, const uint32_t* __restrict__ nzflag,
-                                            BlockMeta* __restrict__ meta, uint64_t* __restrict__ scan_state, const CrcConsts* __restrict__ cc,
-                                            uint8_t* __restrict__ dst, uint64_t dst_stride, WorkQueues* __restrict__ wq) {
-    FusedLds& d = g_f;
+// scr: 2 * kEncWaves words of LDS.  Two barriers inside (they also publish whatever the caller wrote to LDS before).
+__device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t (&W)[4][4],
+                                                RowCtx (&rc)[4], uint32_t* scr) {
     const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63u;
-    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
-    const uint32_t segmask = nzflag[hb];
-    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-
-    // ---- the block: four granules per lane, straight into registers -------------------------------------------------
-    uint32_t W[4][4];
-    const bool seg_nz = (segmask >> w) & 1u;
+    const bool seg_nz = (segmask >> w) & 1u;  // a wave whose 4 KiB segment is all zero (front-end non-zero map) does not read HBM at all
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t pos = w * 4096u + r * 1024u + l * 16u;
@@ -560,11 +442,7 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
             }
         }
     }
-    uint32_t* myhist = d.p1.whist[w];
-    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) myhist[i] = 0;
-
-    // ---- zero-run context of the wave's rows --------------------------------------------------------------------------
-    // rows[r]: chain element of row r (all-zero flag | zeros at its end); a row cut by the block end closes every run
+    // chain element of every row (all-zero flag | zeros at its end); a row cut by the block end closes every run
     uint32_t rowel[4], rvalid[4], fbz[4];  // fbz: 1 = the row's first byte is a (valid) zero
     uint32_t carry = kZIdentity;
 #pragma unroll
@@ -586,109 +464,186 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
         fbz[r] = (rvalid[r] > 0u && (read_lane(W[r][0], 0) & 0xFFu) == 0u) ? 1u : 0u;
     }
     if (l == 0) {
-        d.scr[w] = carry;
-        d.scr[kEncWaves + w] = fbz[0];
+        scr[w] = carry;
+        scr[kEncWaves + w] = fbz[0];
     }
-    __syncthreads();  // B1 (also: every wave's histogram is zeroed)
-    uint32_t sf = l < (uint32_t)kEncWaves ? d.scr[l] : kZIdentity;
+    __syncthreads();
+    uint32_t sf = l < (uint32_t)kEncWaves ? scr[l] : kZIdentity;
     sf = row_scan_prefix(sf, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
-    uint32_t pre = w ? read_lane(sf, w - 1u) : kZIdentity;  // everything before this wave
-    const uint32_t next_fbz = w + 1u < (uint32_t)kEncWaves ? (uint32_t)__builtin_amdgcn_readfirstlane((int)d.scr[kEncWaves + w + 1u]) : 0u;
-    RowCtx rc[4];
-    {
-        uint32_t c = pre;
+    const uint32_t pre = w ? read_lane(sf, w - 1u) : kZIdentity;  // everything before this wave
+    const uint32_t next_fbz = w + 1u < (uint32_t)kEncWaves ? (uint32_t)__builtin_amdgcn_readfirstlane((int)scr[kEncWaves + w + 1u]) : 0u;
+    uint32_t c = pre;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rc[r].zb0 = c & ~kZAll;
-            rc[r].valid = rvalid[r];
-            rc[r].nz_after = r < 3 ? (fbz[r + 1] ? 0u : 1u) : (next_fbz ? 0u : 1u);  // (a row past the block end has fbz = 0: "non-zero")
-            c = zcomb(c, rowel[r]);
-        }
+    for (int r = 0; r < 4; ++r) {
+        rc[r].zb0 = c & ~kZAll;
+        rc[r].valid = rvalid[r];
+        rc[r].nz_after = r < 3 ? (fbz[r + 1] ? 0u : 1u) : (next_fbz ? 0u : 1u);  // (a row past the block end has fbz = 0: "non-zero")
+        c = zcomb(c, rowel[r]);
     }
+    __syncthreads();  // scr may be reused by the caller
+}
 
-    // ---- histogram pass ---------------------------------------------------------------------------------------------
+// rotate the rows through W[0] / rc[0]: the row bodies exist once in the instruction stream; four turns put everything back
+__device__ __forceinline__ void rotate_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4]) {
+    const uint32_t t0 = W[0][0], t1 = W[0][1], t2 = W[0][2], t3 = W[0][3];
+    const RowCtx tc = rc[0];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        W[q][0] = W[q + 1][0];
+        W[q][1] = W[q + 1][1];
+        W[q][2] = W[q + 1][2];
+        W[q][3] = W[q + 1][3];
+        rc[q] = rc[q + 1];
+    }
+    W[3][0] = t0;
+    W[3][1] = t1;
+    W[3][2] = t2;
+    W[3][3] = t3;
+    rc[3] = tc;
+}
+
+__device__ __forceinline__ void hist_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t* myhist, const uint32_t* runcls, uint32_t* queue) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
         if (row_is_dense(W[0], rc[0]))
-            hist_row_dense(W[0], rc[0], myhist, d.runcls);
+            hist_row_dense(W[0], rc[0], myhist, runcls);
         else
-            hist_row_sparse(W[0], rc[0], myhist, d.runcls, d.p1.queue[w]);
-        {  // rotate: the body exists once, the rows pass through W[0]; four turns put everything back
-            uint32_t t0 = W[0][0], t1 = W[0][1], t2 = W[0][2], t3 = W[0][3];
-            const RowCtx tc = rc[0];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                W[q][0] = W[q + 1][0];
-                W[q][1] = W[q + 1][1];
-                W[q][2] = W[q + 1][2];
-                W[q][3] = W[q + 1][3];
-                rc[q] = rc[q + 1];
-            }
-            W[3][0] = t0;
-            W[3][1] = t1;
-            W[3][2] = t2;
-            W[3][3] = t3;
-            rc[3] = tc;
-        }
+            hist_row_sparse(W[0], rc[0], myhist, runcls, queue);
+        rotate_rows(W, rc);
     }
-    __syncthreads();  // B2
-    if (tid < (uint32_t)kSymStride) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int wv = 0; wv < kEncWaves; ++wv) t += d.p1.whist[wv][tid];
-        d.p1.bhist[tid] = t;
-    }
-    __syncthreads();  // B3
+}
 
-    // ---- tree (one wave) ------------------------------------------------------------------------------------------------
-    if (w == 0) {
-        const TreeOut r = build_tree(d.p1.tree, d.p1.bhist, in_size, [&](uint32_t sym, uint32_t code, uint32_t len) { d.tab[sym] = make_uint2(code, len); });
-        if (r.mode == kModeHuff)
-            for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) d.tdesc[i] = d.p1.tree.tdesc[i];
-        if (l == 0) {
-            d.blk[0] = r.mode;
-            d.blk[1] = r.payload_len;
-            d.blk[2] = r.tree_bits;
-            d.blk[3] = r.ntok;
-            d.blk[4] = r.fill;
-            // the size is final: let the blocks behind this one find their offsets
-            scan_publish(scan_state, hb, kScanAgg | (7ull + r.payload_len));
-            meta[hb] = BlockMeta{r.mode, r.payload_len, r.tree_bits, r.mode == kModeHuff ? r.ntok : r.fill};
-        }
-    }
-    __syncthreads();  // B4
-    const uint32_t mode = d.blk[0], L = d.blk[1], tree_bits = d.blk[2], ntok = d.blk[3];
-    if (mode == kModeFill) return;  // one distinct value: k_layout writes the 8 bytes (EncodeFill, hzr_encode.c:341-367)
+// ===========================================================================
+// k_hist
+// ===========================================================================
+// Every wave counts the tokens whose LAST byte lies in its own 4 KiB segment into its own LDS histogram.  Two results:
+//   hist     [hb][264] u32     the block's histogram (sum of the 16), input of k_tree
+//   seghist  [hb][16][264] u16 the per-segment histograms: with the code lengths they give k_tree the stream bit
+//                              at which each segment's tokens start, so k_encode needs no bit-count pass and no
+//                              cross-wave prefix of its own (a 4 KiB segment holds <= 4096 + 4 tokens: u16 is enough)
+struct HistLds {
+    uint32_t hist[kEncWaves][kSymStride];
+    uint32_t queue[kEncWaves][kQueueEntries];
+    uint32_t runcls[kRunClsEntries];
+    uint32_t scr[2 * kEncWaves];
+    uint32_t slot;
+};
+__shared__ HistLds g_h;
 
-    uint32_t base = 0;
-    if (mode == kModeHuff) {
-        // stream bit at which this wave's tokens start: its histogram x the code lengths, prefix over the waves
-        uint32_t bits = 0;
-        for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * d.p1.tree.key[s];  // (unused symbols: count 0)
-        bits = wave_add_u32(bits);
-        if (l == 0) d.wsum[w] = bits;
-        // clean-block invariant: a light block leaves zeros behind.  Each lane is the only reader of its granules.
-        if (ntok <= kWipeTokens) {
+__global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
+                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
+                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total) {
+    HistLds& d = g_h;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
+    if (threadIdx.x < kRunClsEntries) d.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
+    WorkItem wi;
+    for (uint32_t pass = 0; next_work(counter, total, g, &d.slot, wi, pass); ++pass) {
+        const uint32_t tid = thread_id();
+        const uint32_t j = wi.j, k = wi.k, b = wi.b;
+        const uint32_t hb = hb_index(g, b, k, j);
+        const uint32_t nbu = nbuse[b];
+        const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
+        if (k >= nbu) continue;
+        if ((uint32_t)__popc(segmask) <= kSmallSegments) continue;  // all zero (k_tree: Fill(0)) or small (k_tree takes the histogram itself)
+        const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+        const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+        uint32_t W[4][4];
+        RowCtx rc[4];
+        load_block_rows(in, in_size, segmask, W, rc, d.scr);  // (its barriers also order the zeroing below against this block's adds)
+        hist_rows(W, rc, d.hist[tid >> 6], d.runcls, d.queue[tid >> 6]);
+        __syncthreads();
+        if (tid < (uint32_t)kSymStride) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int wv = 0; wv < kEncWaves; ++wv) t += d.hist[wv][tid];
+            hist[(size_t)hb * kSymStride + tid] = t;
+        }
+        uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2);
+        for (uint32_t q = tid; q < kSegHistStride / 2; q += kEncThreads) {
+            const uint32_t lo = (&d.hist[0][0])[2 * q], hi = (&d.hist[0][0])[2 * q + 1];
+            sh[q] = lo | (hi << 16);
+        }
+        __syncthreads();  // everyone has read the histograms
+        for (uint32_t i = tid; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
+    }
+}
+
+// ===========================================================================
+// k_encode
+// ===========================================================================
+struct EncRowsLds {
+    uint2 tab[kSymStride];  // {code, length} per lookup index; 261..263 = {0, 0} (a byte that ends no token)
+    uint32_t crc[4][256];   // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
+    uint32_t runcls[kRunClsEntries];
+    uint32_t scr[2 * kEncWaves];
+    uint32_t wsum[kEncWaves];
+    uint32_t crc_out;
+    uint32_t slot;
+    uint32_t stage[kStagePhys];  // X || payload (+ read slack); light blocks queue sparse-row entries in its tail
+};
+static_assert(sizeof(EncRowsLds) <= 80 * 1024, "two workgroups per CU");
+__shared__ EncRowsLds g_e;
+
+__device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restrict__ planes, const Geom& g, const uint32_t* __restrict__ nzflag,
+                                                  const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
+                                                  const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
+                                                  const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                                  const uint32_t* __restrict__ segbase) {
+    EncRowsLds& d = g_e;
+    const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+    // three independent loads in one round trip (their addresses depend on the block index only)
+    const BlockMeta m = meta[hb];
+    const uint64_t off = out_off[hb];
+    const uint32_t segmask = nzflag[hb];
+    if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
+    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63u;
+    uint8_t* o = dst + (size_t)b * dst_stride + off;
+    const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+    uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    const uint32_t L = m.payload_len;
+    const uint32_t zwords = ((L + 4u) >> 2) + 24u;  // the part of the image the payload (and the CRC's read slack) touches
+
+    uint32_t W[4][4];
+    RowCtx rc[4];
+    if (m.mode == kModeHuff) {
+        const uint32_t first_base = segbase[(size_t)hb * kEncWaves];  // 0xFFFFFFFF: no offsets from k_tree (its own-histogram blocks)
+        uint32_t base = segbase[(size_t)hb * kEncWaves + w];           // stream bit at which this wave's tokens start
+        if (tid < (uint32_t)kSymStride) {
+            const uint32_t c = tid < (uint32_t)kNumSym ? cw[(size_t)hb * kSymStride + tid] : 0u;
+            d.tab[tid] = make_uint2(c & 0x00FFFFFFu, c >> 24);
+        }
+        const bool own_bits = first_base == 0xFFFFFFFFu;  // (block-uniform)
+        if (!own_bits)
+            for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+        load_block_rows(in, in_size, segmask, W, rc, d.scr);  // barriers inside publish the table and the zeroed image
+        if (own_bits) {
+            // the block's histogram was taken by k_tree in one piece (few non-zero segments, but too big for
+            // k_encode_small): count this wave's tokens here -- histogram in the (still unused) image, times the code lengths
+            uint32_t* myhist = d.stage + w * kSymStride;
+            for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) myhist[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            hist_rows(W, rc, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries);
+            __builtin_amdgcn_wave_barrier();
+            uint32_t bits = 0;
+            for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * (d.tab[s].y + run_extra_bits(s));  // (unused symbols: count 0)
+            bits = wave_add_u32(bits);
+            if (l == 0) d.wsum[w] = bits;
+            __syncthreads();
+            uint32_t ws = l < (uint32_t)kEncWaves ? d.wsum[l] : 0u;
+            ws = row_scan_prefix(ws, 0u, [](uint32_t a, uint32_t c) { return a + c; });
+            base = 32u + m.tree_bits + (w ? read_lane(ws, w - 1u) : 0u);  // the payload starts at image byte 4
+            for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+            __syncthreads();
+        }
+        if (block_is_wiped(m)) {
+            // clean-block invariant: a light block leaves zeros behind.  Each lane is the only reader of its granules.
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (W[r][0] | W[r][1] | W[r][2] | W[r][3]) *reinterpret_cast<uint4*>(in + w * 4096u + r * 1024u + l * 16u) = make_uint4(0, 0, 0, 0);
         }
-    }
-    __syncthreads();  // B5: wsum complete, nobody reads the phase-1 scratch any more
-    if (mode == kModeHuff) {
-        uint32_t ws = l < (uint32_t)kEncWaves ? d.wsum[l] : 0u;
-        ws = row_scan_prefix(ws, 0u, [](uint32_t a, uint32_t c) { return a + c; });
-        base = 32u + tree_bits + (w ? read_lane(ws, w - 1u) : 0u);  // the payload starts at image byte 4
-    }
-    // zero the part of the image the payload (and the CRC's read slack) touches; bits are OR-ed in
-    {
-        const uint32_t zwords = ((L + 4u) >> 2) + 24u;
-        for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
-    }
-    __syncthreads();  // B6
-    if (mode == kModeHuff) {
-        const uint32_t twords = (tree_bits + 31u) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
-        if (tid < twords) atomicOr(&d.stage[1u + tid], d.tdesc[tid]);
+        const uint32_t twords = (m.tree_bits + 31u) >> 5;  // tree description (hzr_encode.c:177-219), from logical word 1
+        if (tid < twords) atomicOr(&d.stage[1u + tid], tdesc[(size_t)hb * kTdescWords + tid]);
         uint32_t* queue = L < kLightPayload ? d.stage + kTokQueueBase + w * kQueueEntries : nullptr;
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
@@ -696,26 +651,12 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
                 emit_row_dense(W[0], rc[0], d.tab, d.runcls, d.stage, base);
             else
                 emit_row_sparse(W[0], rc[0], d.tab, d.runcls, d.stage, base, queue);
-        {  // rotate: the body exists once, the rows pass through W[0]; four turns put everything back
-            uint32_t t0 = W[0][0], t1 = W[0][1], t2 = W[0][2], t3 = W[0][3];
-            const RowCtx tc = rc[0];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                W[q][0] = W[q + 1][0];
-                W[q][1] = W[q + 1][1];
-                W[q][2] = W[q + 1][2];
-                W[q][3] = W[q + 1][3];
-                rc[q] = rc[q + 1];
-            }
-            W[3][0] = t0;
-            W[3][1] = t1;
-            W[3][2] = t2;
-            W[3][3] = t3;
-            rc[3] = tc;
-        }
+            rotate_rows(W, rc);
         }
     } else {
-        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block, from the registers
+        // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
+        for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+        load_block_rows(in, in_size, segmask, W, rc, d.scr);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const uint32_t pos = w * 4096u + r * 1024u + l * 16u;
@@ -726,31 +667,18 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
         }
     }
     if (tid == 0) atomicOr(&d.stage[0], cc->prefix);  // X (word 0 was zeroed above)
-    __syncthreads();  // B7
+    __syncthreads();
 
-    // ---- stream offset: wave 0 walks back over the sizes published before this block ------------------------------------
-    if (w == 0) {
-        bool failed;
-        const uint32_t hb0 = hb_index(g, b, 0, 0);
-        const uint64_t excl = scan_lookback(scan_state, hb, hb0, failed);
-        if (l == 0) {
-            const uint64_t off = failed ? ~0ull : 1ull + g.hdr_len + 8ull * (k + 1u) + excl;
-            d.blk[6] = (uint32_t)off;
-            d.blk[7] = (uint32_t)(off >> 32);
-            if (failed)
-                atomicOr(&wq->error, 1u);
-            scan_publish(scan_state, hb, kScanPre | (excl + 7ull + L));  // (after a failure: still a value, so that nobody spins on it)
-        }
-    }
-
-    // ---- CRC-32C: V = X || payload as 4-byte virtual words counted from its END (tools/kernel_model.py:crc_strided) --------
+    // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0) as 4-byte virtual words counted from its END;
+    //      lane tid owns the words tid, tid + 1024, ... (consecutive lanes read consecutive LDS words), Horner over its
+    //      words with x^(8*4096) per step, then x^(8*4*(tid+1)) to the end of V; crc = ~raw(V) -------------------------
     {
         const int32_t Lv = (int32_t)L + 4;
         const uint32_t nvw = (uint32_t)(Lv + 3) >> 2;
-        const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;
-        auto vword = [&](uint32_t r) -> uint32_t {
+        const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;  // steps of the fullest lane (block-uniform)
+        auto vword = [&](uint32_t r) -> uint32_t {  // bytes [Lv - 4(r+1), Lv - 4r) of V; bytes in front of V are zero
             const int32_t lo = Lv - 4 * (int32_t)(r + 1);
-            const int32_t a = lo >> 2;
+            const int32_t a = lo >> 2;  // arithmetic: floor
             const uint32_t w_lo = a >= 0 ? d.stage[a] : 0u, w_hi = d.stage[a + 1];
             return __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)lo & 3u);
         };
@@ -759,29 +687,26 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
             for (uint32_t kk = K - 1; kk >= 1; --kk) {
                 const uint32_t r = tid + kEncThreads * kk;
                 if (r < nvw) c ^= vword(r);
-                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];
+                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];  // * x^(8*4096)
             }
             c ^= vword(tid);
         }
-        if (__ballot(c != 0)) {
-            const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));
-            if (l == 0) d.wsum[w] = gf_shift(cc, 63u - 4u * w, red);
+        if (__ballot(c != 0)) {  // waves without data skip the shifts
+            const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));    // every lane to the end of the wave's 64 words
+            if (l == 0) d.wsum[w] = gf_shift(cc, 63u - 4u * w, red);  // x^(8*256*w): the wave's group to the end of V
         } else if (l == 0) {
             d.wsum[w] = 0;
         }
-        __syncthreads();  // B8
+        __syncthreads();
         if (tid == 0) {
             uint32_t t = 0;
             for (int i = 0; i < kEncWaves; ++i) t ^= d.wsum[i];
             d.crc_out = ~t;
         }
-        __syncthreads();  // B9
+        __syncthreads();
     }
 
-    // ---- block header + payload to the stream (hzr_encode.c:475-481) -----------------------------------------------------
-    const uint64_t off = (uint64_t)d.blk[6] | ((uint64_t)d.blk[7] << 32);
-    if (off == ~0ull || off + 7ull + L > dst_stride) return;  // (the stream does not fit: k_layout flags it)
-    uint8_t* o = dst + (size_t)b * dst_stride + off;
+    // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
     if (tid == 0) {
         const uint32_t crc = d.crc_out;
         o[0] = (uint8_t)(L - 1);
@@ -790,7 +715,7 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
         o[3] = (uint8_t)(crc >> 8);
         o[4] = (uint8_t)(crc >> 16);
         o[5] = (uint8_t)(crc >> 24);
-        o[6] = (uint8_t)mode;
+        o[6] = (uint8_t)m.mode;
     }
     uint8_t* po = o + 7;
     const uint32_t head = min(L, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(po) & 3u)) & 3u));
@@ -799,28 +724,28 @@ __device__ __forceinline__ void fused_block(uint32_t hb, uint8_t* __restrict__ p
     if (tid < head) po[tid] = (uint8_t)stage_byte(d.stage, 4 + tid);
     if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)stage_byte(d.stage, 4 + head + 4 * nd + tid);
     uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
+    // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
     for (uint32_t i = tid; i < nd; i += kEncThreads) pw[i] = __builtin_amdgcn_alignbyte(d.stage[i + 2], d.stage[i + 1], head);
 }
 
-__global__ __launch_bounds__(kEncThreads, 8) void k_fused(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
-                                                         BlockMeta* __restrict__ meta, uint64_t* __restrict__ scan_state,
-                                                         const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                                         WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list, uint32_t nhb_total) {
-    (&g_f.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
-    if (threadIdx.x < kRunClsEntries) g_f.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
-    if (threadIdx.x >= 261 && threadIdx.x < (uint32_t)kSymStride) g_f.tab[threadIdx.x] = make_uint2(0u, 0u);
-    const uint32_t n_big = wq->n_big, n_all = n_big + wq->n_big2;
-    // persistent: blocks are claimed in stream order from ONE counter (no static first item: a claimed block must belong to
-    // a running workgroup, or the look-back of a later block could wait for one that has not started)
-    for (;;) {
+__global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+                                                          const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
+                                                          const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
+                                                          const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
+                                                          WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list,
+                                                          const uint32_t* __restrict__ segbase) {
+    (&g_e.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
+    if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
+    const uint32_t n_big = wq->n_big;
+    // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
+    // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
+    for (uint32_t pass = 0;; ++pass) {
         __syncthreads();  // everyone is done with the previous block (and with the slot)
-        if (threadIdx.x == 0) g_f.slot = atomicAdd(&wq->next_big, 1u);
+        if (threadIdx.x == 0) g_e.slot = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(&wq->next_big, 1u);
         __syncthreads();
-        const uint32_t i = g_f.slot;
-        if (i >= n_all) break;
-        // (after the ordered list: the small-class blocks k_tree handed over; their sizes were published by k_tree)
-        const uint32_t hb = i < n_big ? big_list[i] : big_list[nhb_total - 1u - (i - n_big)];
-        fused_block(hb, planes, g, nzflag, meta, scan_state, cc, dst, dst_stride, wq);
+        const uint32_t i = g_e.slot;
+        if (i >= n_big) break;
+        encode_block_rows(big_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, segbase);
     }
 }
 

@@ -21,7 +21,7 @@
 // unity build: the kernels live in the same translation unit
 #include "preprocess.hip"
 #include "hzr_kernels.hip"
-#include "hzr_fused.hip"
+#include "hzr_rows.hip"
 #include "transforms.hip"
 #include "decode.hip"
 
@@ -94,8 +94,8 @@ void make_crc_consts(CrcConsts& cc) {
     cc.pad[0] = cc.pad[1] = cc.pad[2] = 0;
 }
 
-enum Stage { ST_PRE = 0, ST_NB, ST_LIST, ST_TREE, ST_FUSED, ST_LAYOUT, ST_ENCODE_SMALL, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"preprocess", "nb_scan", "hzr_biglist", "hzr_tree_small", "hzr_fused", "layout", "hzr_encode_small"};
+enum Stage { ST_PRE = 0, ST_NB, ST_HIST, ST_TREE, ST_LAYOUT, ST_ENCODE, ST_ENCODE_SMALL, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"preprocess", "nb_scan", "hzr_hist", "hzr_tree", "layout", "hzr_encode", "hzr_encode_small"};
 
 }  // namespace
 
@@ -128,8 +128,10 @@ struct rspt_hip_packer {
     uint32_t dirty_shift = 0;
     bool planes_unknown = false;      // something else (decompress, a diagnostic run) wrote the planes: flag them all
     uint32_t* nb_state = nullptr;  // [4] persistent: [0] = nb; [2] = work counter of the decoder's persistent grid (zeroed by k_dec_frame)
-    uint64_t* scan_state = nullptr;  // [cap*4*nblk] stream-offset scan: flag << 62 | encoded size / prefix (zeroed per call)
-    uint32_t* cw = nullptr;        // [cap*4*nblk][264] code words of the small blocks (k_tree -> k_encode_small)
+    uint32_t* hist = nullptr;      // [cap*4*nblk][264]
+    uint32_t* seghist = nullptr;   // [cap*4*nblk][16][264] u16: tokens ending in each 4 KiB segment (k_hist -> k_tree)
+    uint32_t* segbase = nullptr;   // [cap*4*nblk][16] stream bit at which each segment's tokens start (k_tree -> k_encode)
+    uint32_t* cw = nullptr;        // [cap*4*nblk][264] code | length << 24 per symbol
     uint32_t* tdesc = nullptr;     // [..][92]
     BlockMeta* meta = nullptr;     // [..]
     uint64_t* out_off = nullptr;   // [..]
@@ -354,7 +356,10 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->big_list);
     hipFree(p->small_list);
     p->nzflag = p->big_list = p->small_list = nullptr;
-    p->scan_state = nullptr;  // (lives inside the nzflag allocation)
+    hipFree(p->hist);
+    hipFree(p->seghist);
+    hipFree(p->segbase);
+    p->seghist = p->segbase = nullptr;
     hipFree(p->cw);
     hipFree(p->tdesc);
     hipFree(p->meta);
@@ -373,7 +378,7 @@ static void free_workspace(rspt_hip_packer* p) {
     p->blk_off = nullptr;
     p->planes = nullptr;
     p->planar = nullptr;
-    p->needmask = p->nbuse = p->cw = p->tdesc = nullptr;
+    p->needmask = p->nbuse = p->hist = p->cw = p->tdesc = nullptr;
     p->meta = nullptr;
     p->out_off = nullptr;
     p->means = nullptr;
@@ -630,10 +635,13 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->plane_dirty, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
-    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32 + 2 * max_blocks * (size_t)g.nch + 2 + 2 * nhb + 2) * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32 + 2 * max_blocks * (size_t)g.nch + 2) * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->cw, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->seghist, nhb * (size_t)kSegHistStride * sizeof(uint16_t)) == hipSuccess;
+    ok &= hipMalloc(&p->segbase, nhb * (size_t)kEncWaves * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->tdesc, nhb * kTdescWords * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->meta, nhb * sizeof(BlockMeta)) == hipSuccess;
     ok &= hipMalloc(&p->out_off, nhb * sizeof(uint64_t)) == hipSuccess;
@@ -684,9 +692,6 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         p->needmask = p->nzflag + nhb_call;
         p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
         size_t zwords = (size_t)((p->work_ctr + 16) - p->nzflag);
-        zwords = (zwords + 1) & ~(size_t)1;  // the stream-offset scan words (u64), zeroed with everything else
-        p->scan_state = reinterpret_cast<uint64_t*>(p->nzflag + zwords);
-        zwords += 2 * nhb_call;
         p->row_sum = nullptr;
         p->have_row_sum = false;
         if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {  // channel sums of the de-interleave pass, 8-byte aligned behind the counters
@@ -745,33 +750,35 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         }
     }
 
-    stamp(p, ST_LIST, st);
+    stamp(p, ST_HIST, st);
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
-    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
-    // the hzr stage: small / empty blocks are settled by one wave each (k_tree: histogram, tree, size), everything else by
-    // the fused workgroup-per-block encoder, which finds its stream offsets by look-back over the published sizes
-    hipLaunchKernelGGL(k_biglist, dim3(1), dim3(1024), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, wq);
+    const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
+    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->work_ctr, nhb);
 
     stamp(p, ST_TREE, st);
-    hipLaunchKernelGGL(k_tree, dim3((nhb + kTreeWaves - 1) / kTreeWaves), dim3(kTreeWaves * 64), 0, st, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw,
-                       p->tdesc, p->meta, p->scan_state, wq, p->big_list);
-
-    stamp(p, ST_FUSED, st);
-    const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
-    hipLaunchKernelGGL(k_fused, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->scan_state, p->crc, (uint8_t*)d_dst,
-                       (uint64_t)dst_stride, wq, p->big_list, nhb);
+    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
 
     stamp(p, ST_LAYOUT, st);
+    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
-                       d_sizes, p->crc, p->nzflag, wq, p->small_list, p->plane_dirty, p->dirty_shift);
+                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift);
 
-    stamp(p, ST_ENCODE_SMALL, st);
+    stamp(p, ST_ENCODE, st);
     {
+        // both encoders depend on k_layout only.  The small-block one goes to the side stream: the big one's persistent
+        // workgroups hold every wave slot, so the small blocks start as those retire and fill its tail.
+        HIPCHK(p, hipEventRecord(p->ev_fork, st));
+        HIPCHK(p, hipStreamWaitEvent(p->side, p->ev_fork, 0));
         const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
         const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
-        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc,
+        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, p->side, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc,
                            p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate);
+        HIPCHK(p, hipEventRecord(p->ev_join, p->side));
     }
+    hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
+                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase);
+    stamp(p, ST_ENCODE_SMALL, st);
+    HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
@@ -1006,7 +1013,7 @@ long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, siz
         case 0: src = p->planes; n = p->cap_blocks * kMaxPlanes * g.plane_stride; break;
         case 1: src = p->planar; n = p->cap_blocks * (size_t)g.N * 4; break;
         case 2: src = p->planar2; n = p->planar2 ? p->cap_blocks * (size_t)g.N * 4 : 0; break;
-        case 3: src = p->scan_state; n = nhb * 8; break;
+        case 3: src = p->hist; n = nhb * kSymStride * 4; break;
         case 4: src = p->meta; n = nhb * sizeof(BlockMeta); break;
         case 5: src = p->nbuse; n = p->cap_blocks * 4; break;
         case 6: src = p->means; n = p->cap_blocks * (size_t)g.hdr_len; break;
