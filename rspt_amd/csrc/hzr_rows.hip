@@ -111,21 +111,26 @@ struct RowCtx {
 // ===========================================================================
 // dense rows: scalar zero masks per byte position
 // ===========================================================================
+// Scalar and vector pipes issue one wave instruction per cycle and CU each, so the mask logic is kept to six scalar
+// operations per byte position (next to ~5 vector ones): with ZZ(i) = z(i) & z(i+1) ("a zero followed by a zero")
+//   A(i)    = ZZ(i-1) & ~z(i+1)   a run of two or more zeros ends here
+//   Len2(i) = A(i) & ~z(i-2)      ... of exactly two: lookup index 256
+//   Long(i) = A(i) &  z(i-2)      ... of three or more: handled per lane afterwards
+//   Dead(i) = ZZ(i) | Long(i)     zero bytes that end no token (a zero that ends a run of one is a lookup of index 0)
 struct DenseMasks {
     unsigned long long Z[16];
-    unsigned long long c1, c2, cz;
-    __device__ __forceinline__ unsigned long long p1(int i) const { return i >= 1 ? Z[i - 1] : ((Z[15] << 1) | c1); }
-    __device__ __forceinline__ unsigned long long p2(int i) const {
-        return i >= 2 ? Z[i - 2] : i == 1 ? ((Z[15] << 1) | c1) : ((Z[14] << 1) | c2);
-    }
-    __device__ __forceinline__ unsigned long long nx(int i) const { return i <= 14 ? Z[i + 1] : ((Z[0] >> 1) | cz); }
+    unsigned long long z15s, z14s, z0n;  // z(-1), z(-2) and z(16) of every lane: the neighbours' bytes, the row's surroundings at the ends
+    __device__ __forceinline__ unsigned long long p1(int i) const { return i >= 1 ? Z[i - 1] : z15s; }
+    __device__ __forceinline__ unsigned long long p2(int i) const { return i >= 2 ? Z[i - 2] : i == 1 ? z15s : z14s; }
+    __device__ __forceinline__ unsigned long long nx(int i) const { return i <= 14 ? Z[i + 1] : z0n; }
 };
 __device__ __forceinline__ void dense_masks(const uint32_t (&w)[4], const RowCtx& rc, DenseMasks& M) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) M.Z[i] = __ballot(((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) == 0u);
-    M.c1 = rc.zb0 >= 1 ? 1ull : 0ull;
-    M.c2 = rc.zb0 >= 2 ? 1ull : 0ull;
-    M.cz = rc.nz_after ? 0ull : (1ull << 63);
+    const uint32_t zb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.zb0), nza = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.nz_after);
+    M.z15s = (M.Z[15] << 1) | (zb0 >= 1 ? 1ull : 0ull);
+    M.z14s = (M.Z[14] << 1) | (zb0 >= 2 ? 1ull : 0ull);
+    M.z0n = (M.Z[0] >> 1) | (nza ? 0ull : (1ull << 63));
 }
 
 // per-lane view of the same row, for the lanes that hold a run of three or more zeros (or a slow quad)
@@ -154,19 +159,21 @@ __device__ __forceinline__ void hist_row_dense(const uint32_t (&w)[4], const Row
     DenseMasks M;
     dense_masks(w, rc, M);
     unsigned long long longany = 0;
+    unsigned long long zzprev = M.z15s & M.Z[0];  // ZZ(-1)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const unsigned long long P1 = M.p1(i), P2 = M.p2(i);
-        const unsigned long long End = M.Z[i] & ~M.nx(i);
-        const unsigned long long Len2 = End & P1 & ~P2;
-        const unsigned long long Dead = M.Z[i] & ~(End & ~P1) & ~Len2;  // zero bytes that are neither a run of one nor the end of a run of two
+        const unsigned long long Nx = M.nx(i);
+        const unsigned long long ZZ = M.Z[i] & Nx;
+        const unsigned long long A = zzprev & ~Nx;
+        const unsigned long long P2 = M.p2(i);
+        const unsigned long long Len2 = A & ~P2, Long = A & P2;
+        const unsigned long long Dead = ZZ | Long;
         uint32_t idx = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-        if (Dead | Len2) {
-            idx = lane_bit(Dead) ? 261u : idx;
-            idx = lane_bit(Len2) ? 256u : idx;
-        }
+        idx = lane_bit(Dead) ? 261u : idx;  // (bins 261..263 are never read)
+        idx = lane_bit(Len2) ? 256u : idx;
         atomicAdd(&h[idx], 1u);
-        longany |= End & P1 & P2;
+        longany |= Long;
+        zzprev = ZZ;
     }
     if (longany) {
         const LaneView v = lane_view(w, rc, M);
@@ -185,40 +192,41 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
     DenseMasks M;
     dense_masks(w, rc, M);
     unsigned long long longany = 0;
+    unsigned long long zzprev = M.z15s & M.Z[0];  // ZZ(-1)
     uint32_t qlo[4], qhi[4], qlen[4];
     uint32_t slow = 0;  // bit q: quad q is emitted token by token
 #pragma unroll
-    for (int h8 = 0; h8 < 16; h8 += 8) {
-        uint2 c[8];
+    for (int qd = 0; qd < 4; ++qd) {
+        uint2 c[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int i = h8 + e;
-            const unsigned long long P1 = M.p1(i), P2 = M.p2(i);
-            const unsigned long long End = M.Z[i] & ~M.nx(i);
-            const unsigned long long Len2 = End & P1 & ~P2;
-            const unsigned long long Dead = M.Z[i] & ~(End & ~P1) & ~Len2;
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * qd + e;
+            const unsigned long long Nx = M.nx(i);
+            const unsigned long long ZZ = M.Z[i] & Nx;
+            const unsigned long long A = zzprev & ~Nx;
+            const unsigned long long P2 = M.p2(i);
+            const unsigned long long Len2 = A & ~P2, Long = A & P2;
+            const unsigned long long Dead = ZZ | Long;
             uint32_t idx = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-            if (Dead | Len2) {
-                idx = lane_bit(Dead) ? 261u : idx;
-                idx = lane_bit(Len2) ? 256u : idx;
-            }
+            idx = lane_bit(Dead) ? 261u : idx;  // {0, 0}
+            idx = lane_bit(Len2) ? 256u : idx;
             c[e] = tab[idx];
-            longany |= End & P1 & P2;
+            longany |= Long;
+            zzprev = ZZ;
         }
+        __builtin_amdgcn_sched_barrier(0);  // four lookups in flight, one wait
+        const uint32_t s1 = c[0].y + c[1].y, s2 = c[2].y + c[3].y;
+        const uint32_t v01 = c[0].x | (c[1].x << (c[0].y & 31u));
+        const uint32_t v23 = c[2].x | (c[3].x << (c[2].y & 31u));
+        const uint64_t V = (uint64_t)v01 | ((uint64_t)v23 << (s1 & 63u));
+        qlo[qd] = (uint32_t)V;
+        qhi[qd] = (uint32_t)(V >> 32);
+        qlen[qd] = s1 + s2;
+        if ((s1 > 32u) | (s2 > 32u)) slow |= 1u << qd;  // a pair of codes longer than 32 bits (deep trees only)
+        // pin the quad's string here: left to itself the scheduler sums the lengths first (they feed the scan) and parks all
+        // sixteen table entries in scratch until the strings are joined after it
+        asm volatile("" : "+v"(qlo[qd]), "+v"(qhi[qd]), "+v"(qlen[qd]), "+v"(slow));
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-            const int qd = (h8 >> 2) + qq;
-            const uint2 c0 = c[4 * qq], c1 = c[4 * qq + 1], c2 = c[4 * qq + 2], c3 = c[4 * qq + 3];
-            const uint32_t s1 = c0.y + c1.y, s2 = c2.y + c3.y;
-            const uint32_t v01 = c0.x | (c1.x << (c0.y & 31u));
-            const uint32_t v23 = c2.x | (c3.x << (c2.y & 31u));
-            const uint64_t V = (uint64_t)v01 | ((uint64_t)v23 << (s1 & 63u));
-            qlo[qd] = (uint32_t)V;
-            qhi[qd] = (uint32_t)(V >> 32);
-            qlen[qd] = s1 + s2;
-            if ((s1 > 32u) | (s2 > 32u)) slow |= 1u << qd;
-        }
     }
     LaneView v{};
     const bool anylong = longany != 0;
