@@ -103,10 +103,15 @@ __device__ __forceinline__ uint32_t emit_run(uint32_t* stage, const uint2* tab, 
 
 // what a row needs to know about its surroundings (wave-uniform)
 struct RowCtx {
-    uint32_t zb0;       // zeros immediately before the row's first byte (cut at the block start)
-    uint32_t nz_after;  // 1: the byte behind the row's last valid byte is non-zero, or the block ends there
-    uint32_t valid;     // bytes of this row inside the block (0..1024)
+    uint32_t zb0;    // zeros immediately before the row's first byte (cut at the block start)
+    uint32_t last;   // 1: the block ends with this row's last valid byte
+    uint32_t valid;  // bytes of this row inside the block (0..1024)
+    uint32_t rb;     // position of the row's first byte in the block
 };
+
+// Attribution inside a block, rule B: the tokens of a zero run belong to the byte BEHIND the run (the literal that ends
+// it); a run that reaches the block end belongs to the block's last byte.  Inside a dense row the run's own last byte
+// carries them (the same thing, seen from the scalar masks); what crosses a row boundary is the count `zb0` alone.
 
 // ===========================================================================
 // dense rows: scalar zero masks per byte position
@@ -117,6 +122,7 @@ struct RowCtx {
 //   Len2(i) = A(i) & ~z(i-2)      ... of exactly two: lookup index 256
 //   Long(i) = A(i) &  z(i-2)      ... of three or more: handled per lane afterwards
 //   Dead(i) = ZZ(i) | Long(i)     zero bytes that end no token (a zero that ends a run of one is a lookup of index 0)
+// z(16) of lane 63 is "zero" unless the block ends there: a run that ends with the row is the next row's business.
 struct DenseMasks {
     unsigned long long Z[16];
     unsigned long long z15s, z14s, z0n;  // z(-1), z(-2) and z(16) of every lane: the neighbours' bytes, the row's surroundings at the ends
@@ -127,11 +133,12 @@ struct DenseMasks {
 __device__ __forceinline__ void dense_masks(const uint32_t (&w)[4], const RowCtx& rc, DenseMasks& M) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) M.Z[i] = __ballot(((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) == 0u);
-    const uint32_t zb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.zb0), nza = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.nz_after);
-    M.z15s = (M.Z[15] << 1) | (zb0 >= 1 ? 1ull : 0ull);
-    M.z14s = (M.Z[14] << 1) | (zb0 >= 2 ? 1ull : 0ull);
-    M.z0n = (M.Z[0] >> 1) | (nza ? 0ull : (1ull << 63));
+    M.z15s = (M.Z[15] << 1) | (rc.zb0 >= 1 ? 1ull : 0ull);
+    M.z14s = (M.Z[14] << 1) | (rc.zb0 >= 2 ? 1ull : 0ull);
+    M.z0n = (M.Z[0] >> 1) | (rc.last ? 0ull : (1ull << 63));
 }
+// the run in front of the row, if the row's first byte ends it (lane 0 emits it in front of its first token)
+__device__ __forceinline__ uint32_t lead_run(const RowCtx& rc, const DenseMasks& M) { return (M.Z[0] & 1ull) ? 0u : rc.zb0; }
 
 // per-lane view of the same row, for the lanes that hold a run of three or more zeros (or a slow quad)
 struct LaneView {
@@ -175,6 +182,8 @@ __device__ __forceinline__ void hist_row_dense(const uint32_t (&w)[4], const Row
         longany |= Long;
         zzprev = ZZ;
     }
+    const uint32_t lead = lead_run(rc, M);
+    if (lead && lane_id() == 0) hist_run(h, runcls, lead);
     if (longany) {
         const LaneView v = lane_view(w, rc, M);
         uint32_t t = v.lng;
@@ -245,6 +254,13 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
             slow |= 1u << qd;
         }
     }
+    const uint32_t lead = lane_id() == 0 ? lead_run(rc, M) : 0u;  // the run in front of the row: lane 0, ahead of its first token
+    if (lead_run(rc, M)) {
+        if (lead) {
+            qlen[0] += run_bits_tab(tab, runcls, lead);
+            slow |= 1u;
+        }
+    }
     const uint32_t tot = qlen[0] + qlen[1] + qlen[2] + qlen[3];
     const uint32_t inc = wave_scan_add(tot);
     uint32_t pq[4];
@@ -265,7 +281,10 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
             const uint32_t i = (uint32_t)__builtin_ctz(ts);
             ts &= ts - 1;
             const uint32_t qd = i >> 2;
-            if (qd != prevq) pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
+            if (qd != prevq) {
+                pp = qd == 0 ? pq[0] : qd == 1 ? pq[1] : qd == 2 ? pq[2] : pq[3];
+                if (qd == 0 && lead) pp += emit_run(stage, tab, runcls, pp, lead);  // (its quad 0 starts with the literal that ends the run)
+            }
             prevq = qd;
             if ((v.lng >> i) & 1u) {
                 pp += emit_run(stage, tab, runcls, pp, run_ending_at(i, v.lits, v.zb));
@@ -280,105 +299,106 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
 }
 
 // ===========================================================================
-// sparse rows: per-lane entries.  entry = lit | R << 9: R zeros, then (lit < 256) the literal
+// sparse rows: the row's literals, in order, as (position, value) entries in a per-wave queue; the wave then takes the
+// queue 64 entries at a time -- the run in front of a literal is the gap to the entry before it, so nothing has to be
+// chained from lane to lane.  A row that ends the block appends a virtual entry at in_size (the run that reaches the end).
 // ===========================================================================
 constexpr uint32_t kNoLit = 0x100u;
-struct SparseLane {
-    uint32_t lits, nv, zb;
-    uint32_t tail;   // 1: the granule ends with a run that ends there
-    uint32_t tailR;  // its length
-    uint32_t nent;
-};
-__device__ __forceinline__ SparseLane sparse_lane(const uint32_t (&w)[4], const RowCtx& rc) {
-    SparseLane s;
-    const uint32_t l = lane_id();
-    const int32_t left = (int32_t)rc.valid - (int32_t)(16u * l);
-    s.nv = left <= 0 ? 0u : left >= 16 ? 16u : (uint32_t)left;
-    const uint32_t vmask = (1u << s.nv) - 1u;
-    const uint32_t zr = zero_mask16(w[0], w[1], w[2], w[3]);
-    const uint32_t zm = zr & vmask;
-    s.lits = ~zr & vmask;
-    const bool allz = s.nv == 16u && zm == 0xFFFFu;
-    const uint32_t trail = (s.nv == 16u && !allz) ? trail_zero_bytes(w[0], w[1], w[2], w[3]) : 0u;  // (a partial granule ends the block)
-    s.zb = zeros_before(allz, trail, rc.zb0);
-    const unsigned long long z0 = __ballot(s.nv > 0u && (zm & 1u));
-    const unsigned long long nextz = (z0 >> 1) | (rc.nz_after ? 0ull : (1ull << 63));
-    const bool nextzero = s.nv == 16u && lane_bit(nextz);
-    const bool lastzero = s.nv > 0u && ((zm >> (s.nv - 1u)) & 1u);
-    s.tail = (lastzero && !nextzero) ? 1u : 0u;
-    s.tailR = s.lits ? (s.nv - 1u - (31u - (uint32_t)__clz((int)s.lits))) : s.nv + s.zb;
-    s.nent = (uint32_t)__popc(s.lits) + s.tail;
-    return s;
-}
 
-// f(R, lit): the lane's entries in stream order
-template <class F>
-__device__ __forceinline__ void lane_entries(const uint32_t (&w)[4], const SparseLane& s, F f) {
-    uint32_t t = s.lits, pe = 0;
-    bool first = true;
+// the lane's non-zero bytes (bit i = byte i) -- bytes behind the block end were masked to zero at the load
+__device__ __forceinline__ uint32_t lane_lits(const uint32_t (&w)[4]) { return ~zero_mask16(w[0], w[1], w[2], w[3]) & 0xFFFFu; }
+
+// fills the queue; returns the number of entries (0: nothing ends in this row)
+__device__ __forceinline__ uint32_t sparse_queue(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, uint32_t lits, uint32_t* queue,
+                                                 bool& queued) {
+    const uint32_t l = lane_id();
+    const uint32_t n = (uint32_t)__popc(lits);
+    const uint32_t incl = wave_scan_add(n);
+    const uint32_t T = read_lane(incl, 63) + (rc.last ? 1u : 0u);
+    queued = queue != nullptr && T <= kQueueEntries;
+    if (T == 0 || !queued) return T;
+    uint32_t k = incl - n, t = lits;
+    const uint32_t pos0 = rc.rb + 16u * l;
     while (t) {
         const uint32_t i = (uint32_t)__builtin_ctz(t);
         t &= t - 1;
-        const uint32_t R = first ? (i ? i + s.zb : 0u) : (i - pe);  // (i == 0: a run that ended with the granule before is counted there)
-        f(R, granule_byte_dyn(w[0], w[1], w[2], w[3], i));
-        pe = i + 1u;
-        first = false;
+        queue[k++] = ((pos0 + i) << 9) | granule_byte_dyn(w[0], w[1], w[2], w[3], i);
     }
-    if (s.tail) f(s.tailR, kNoLit);
+    if (rc.last && l == 0) queue[T - 1u] = (in_size << 9) | kNoLit;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return T;
 }
 
-// returns false when the row holds nothing; else fills the queue (if the row fits) and returns the entry count in T
-__device__ __forceinline__ bool sparse_queue(const uint32_t (&w)[4], const SparseLane& s, uint32_t* queue, uint32_t& T) {
-    const uint32_t incl = wave_scan_add(s.nent);
-    T = read_lane(incl, 63);
-    if (T == 0) return false;
-    if (queue && T <= kQueueEntries) {
-        uint32_t k = incl - s.nent;
-        lane_entries(w, s, [&](uint32_t R, uint32_t lit) { queue[k++] = lit | (R << 9); });
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+// entry k of the queue and the zeros in front of it
+__device__ __forceinline__ void queue_entry(const uint32_t* queue, const RowCtx& rc, uint32_t k, uint32_t T, uint32_t& R, uint32_t& lit) {
+    R = 0;
+    lit = kNoLit;
+    if (k < T) {
+        const uint32_t e = queue[k];
+        const uint32_t before = k ? (queue[k - 1u] >> 9) + 1u : rc.rb - rc.zb0;  // position behind the literal before this one
+        lit = e & 0x1FFu;
+        R = (e >> 9) - before;
     }
-    return true;
 }
 
-__device__ __forceinline__ bool row_is_quiet(const uint32_t (&w)[4], const RowCtx& rc) {
-    // nothing but zeros, and the run goes on behind the row: no token ends here
-    return rc.valid == 0u || (rc.valid == 1024u && !rc.nz_after && !__ballot((w[0] | w[1] | w[2] | w[3]) != 0u));
+// without a queue: f(R, lit) for the lane's own entries, in stream order (the gap to the literal of a lower lane comes from a scan)
+template <class F>
+__device__ __forceinline__ void lane_entries(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, uint32_t lits, F f) {
+    const uint32_t l = lane_id();
+    const uint32_t pos0 = rc.rb + 16u * l;
+    const uint32_t mine = lits ? pos0 + (32u - (uint32_t)__clz((int)lits)) : 0u;  // position behind this lane's last literal
+    const uint32_t incl = wave_scan_incl(mine, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    uint32_t before = dpp<0x138>(0u, incl);  // wave_shr:1: behind the last literal of the lanes below
+    before = max(l ? before : 0u, rc.rb - rc.zb0);
+    uint32_t t = lits;
+    while (t) {
+        const uint32_t i = (uint32_t)__builtin_ctz(t);
+        t &= t - 1;
+        f(pos0 + i - before, granule_byte_dyn(w[0], w[1], w[2], w[3], i));
+        before = pos0 + i + 1u;
+    }
+    if (rc.last && l == 63u) f(in_size - max(read_lane(incl, 63), rc.rb - rc.zb0), kNoLit);  // the run that reaches the block end
 }
 
-__device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t* h, const uint32_t* runcls, uint32_t* queue) {
-    if (row_is_quiet(w, rc)) return;
-    const SparseLane s = sparse_lane(w, rc);
-    uint32_t T;
-    if (!sparse_queue(w, s, queue, T)) return;
-    if (T <= kQueueEntries) {
+__device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, uint32_t* h, const uint32_t* runcls,
+                                                uint32_t* queue) {
+    if (rc.valid == 0u) return;
+    if (!rc.last && !__ballot((w[0] | w[1] | w[2] | w[3]) != 0u)) return;  // nothing but zeros, and the block goes on: no token ends here
+    const uint32_t lits = lane_lits(w);
+    bool queued;
+    const uint32_t T = sparse_queue(w, rc, in_size, lits, queue, queued);
+    if (T == 0) return;
+    if (queued) {
         const uint32_t l = lane_id();
         for (uint32_t c = 0; c < T; c += 64) {
-            const uint32_t e = c + l < T ? queue[c + l] : kNoLit;
-            const uint32_t R = e >> 9, lit = e & 0x1FFu;
+            uint32_t R, lit;
+            queue_entry(queue, rc, c + l, T, R, lit);
             if (R) hist_run(h, runcls, R);
             if (lit < 256u) atomicAdd(&h[lit], 1u);
         }
         __builtin_amdgcn_wave_barrier();  // the queue is reused by the next row
     } else {
-        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+        lane_entries(w, rc, in_size, lits, [&](uint32_t R, uint32_t lit) {
             if (R) hist_run(h, runcls, R);
             if (lit < 256u) atomicAdd(&h[lit], 1u);
         });
     }
 }
 
-__device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, const uint2* tab, const uint32_t* runcls, uint32_t* stage,
-                                                uint32_t& base, uint32_t* queue) {
-    if (row_is_quiet(w, rc)) return;
-    const SparseLane s = sparse_lane(w, rc);
-    uint32_t T;
-    if (!sparse_queue(w, s, queue, T)) return;
-    if (queue && T <= kQueueEntries) {
+__device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, const uint2* tab, const uint32_t* runcls,
+                                                uint32_t* stage, uint32_t& base, uint32_t* queue) {
+    if (rc.valid == 0u) return;
+    if (!rc.last && !__ballot((w[0] | w[1] | w[2] | w[3]) != 0u)) return;
+    const uint32_t lits = lane_lits(w);
+    bool queued;
+    const uint32_t T = sparse_queue(w, rc, in_size, lits, queue, queued);
+    if (T == 0) return;
+    if (queued) {
         const uint32_t l = lane_id();
         for (uint32_t c = 0; c < T; c += 64) {
-            const uint32_t e = c + l < T ? queue[c + l] : kNoLit;
-            const uint32_t R = e >> 9, lit = e & 0x1FFu;
+            uint32_t R, lit;
+            queue_entry(queue, rc, c + l, T, R, lit);
             const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
             const uint32_t rem = R - q * kRunCap;
             uint64_t rv = 0;
@@ -399,14 +419,14 @@ __device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const Ro
     } else {
         // no queue (a heavy block's image leaves no room) or a row with too many entries: every lane walks its own, twice
         uint32_t bits = 0;
-        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+        lane_entries(w, rc, in_size, lits, [&](uint32_t R, uint32_t lit) {
             if (R) bits += run_bits_tab(tab, runcls, R);
             if (lit < 256u) bits += tab[lit].y;
         });
         const uint32_t inc = wave_scan_add(bits);
         uint32_t pos = base + inc - bits;
         base += read_lane(inc, 63);
-        lane_entries(w, s, [&](uint32_t R, uint32_t lit) {
+        lane_entries(w, rc, in_size, lits, [&](uint32_t R, uint32_t lit) {
             if (R) pos += emit_run(stage, tab, runcls, pos, R);
             if (lit < 256u) {
                 const uint2 cw = tab[lit];
@@ -423,14 +443,14 @@ __device__ __forceinline__ bool row_is_dense(const uint32_t (&w)[4], const RowCt
     return __popcll(__ballot((w[0] | w[1] | w[2] | w[3]) == 0u)) < 16;
 }
 
-
 // ===========================================================================
 // the block in registers: four granules per lane, and what every row has to know about its surroundings
 // ===========================================================================
-// scr: 2 * kEncWaves words of LDS.  Two barriers inside (they also publish whatever the caller wrote to LDS before).
+// scr: kEncWaves words of LDS.  Two barriers inside (they also publish whatever the caller wrote to LDS before).
 __device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t (&W)[4][4],
                                                 RowCtx (&rc)[4], uint32_t* scr) {
-    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63u;
+    const uint32_t tid = thread_id(), l = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (wave-uniform: keeps the row contexts in scalar registers)
     const bool seg_nz = (segmask >> w) & 1u;  // a wave whose 4 KiB segment is all zero (front-end non-zero map) does not read HBM at all
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -450,43 +470,33 @@ __device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, 
             }
         }
     }
-    // chain element of every row (all-zero flag | zeros at its end); a row cut by the block end closes every run
-    uint32_t rowel[4], rvalid[4], fbz[4];  // fbz: 1 = the row's first byte is a (valid) zero
-    uint32_t carry = kZIdentity;
+    // position behind the last literal of every row (0: the row holds none); the same for the wave, chained over the waves
+    uint32_t behind[4];
+    uint32_t wave_behind = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long nzg = __ballot((W[r][0] | W[r][1] | W[r][2] | W[r][3]) != 0u);
+        behind[r] = 0;
+        if (nzg) {
+            const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nzg);
+            const uint32_t tr = read_lane(trail_zero_bytes(W[r][0], W[r][1], W[r][2], W[r][3]), ph);
+            behind[r] = w * 4096u + r * 1024u + 16u * ph + 16u - tr;
+        }
+        wave_behind = max(wave_behind, behind[r]);
+    }
+    if (l == 0) scr[w] = wave_behind;
+    __syncthreads();
+    uint32_t sf = l < (uint32_t)kEncWaves ? scr[l] : 0u;
+    sf = row_scan_prefix(sf, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; });
+    uint32_t c = w ? read_lane(sf, w - 1u) : 0u;  // behind the last literal before this wave
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const uint32_t rb = w * 4096u + r * 1024u;
-        rvalid[r] = rb >= in_size ? 0u : min(1024u, in_size - rb);
-        const int32_t left = (int32_t)rvalid[r] - (int32_t)(16u * l);
-        const bool full = left >= 16;
-        const bool allz = full && (W[r][0] | W[r][1] | W[r][2] | W[r][3]) == 0u;
-        const uint32_t trail = (full && !allz) ? trail_zero_bytes(W[r][0], W[r][1], W[r][2], W[r][3]) : 0u;
-        const unsigned long long nonall = ~__ballot(allz);
-        uint32_t el = kZAll | 1024u;
-        if (nonall) {
-            const uint32_t ph = 63u - (uint32_t)__builtin_clzll(nonall);
-            el = 16u * (63u - ph) + read_lane(trail, ph);
-        }
-        rowel[r] = el;
-        carry = zcomb(carry, el);
-        fbz[r] = (rvalid[r] > 0u && (read_lane(W[r][0], 0) & 0xFFu) == 0u) ? 1u : 0u;
-    }
-    if (l == 0) {
-        scr[w] = carry;
-        scr[kEncWaves + w] = fbz[0];
-    }
-    __syncthreads();
-    uint32_t sf = l < (uint32_t)kEncWaves ? scr[l] : kZIdentity;
-    sf = row_scan_prefix(sf, kZIdentity, [](uint32_t far, uint32_t near) { return zcomb(far, near); });
-    const uint32_t pre = w ? read_lane(sf, w - 1u) : kZIdentity;  // everything before this wave
-    const uint32_t next_fbz = w + 1u < (uint32_t)kEncWaves ? (uint32_t)__builtin_amdgcn_readfirstlane((int)scr[kEncWaves + w + 1u]) : 0u;
-    uint32_t c = pre;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rc[r].zb0 = c & ~kZAll;
-        rc[r].valid = rvalid[r];
-        rc[r].nz_after = r < 3 ? (fbz[r + 1] ? 0u : 1u) : (next_fbz ? 0u : 1u);  // (a row past the block end has fbz = 0: "non-zero")
-        c = zcomb(c, rowel[r]);
+        rc[r].rb = rb;
+        rc[r].valid = rb >= in_size ? 0u : min(1024u, in_size - rb);
+        rc[r].last = (rc[r].valid > 0u && rb + rc[r].valid == in_size) ? 1u : 0u;
+        rc[r].zb0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rb - min(c, rb)));
+        c = max(c, behind[r]);
     }
     __syncthreads();  // scr may be reused by the caller
 }
@@ -510,13 +520,14 @@ __device__ __forceinline__ void rotate_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4]
     rc[3] = tc;
 }
 
-__device__ __forceinline__ void hist_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t* myhist, const uint32_t* runcls, uint32_t* queue) {
+__device__ __forceinline__ void hist_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t in_size, uint32_t* myhist, const uint32_t* runcls,
+                                          uint32_t* queue) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
         if (row_is_dense(W[0], rc[0]))
             hist_row_dense(W[0], rc[0], myhist, runcls);
         else
-            hist_row_sparse(W[0], rc[0], myhist, runcls, queue);
+            hist_row_sparse(W[0], rc[0], in_size, myhist, runcls, queue);
         rotate_rows(W, rc);
     }
 }
@@ -558,7 +569,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         uint32_t W[4][4];
         RowCtx rc[4];
         load_block_rows(in, in_size, segmask, W, rc, d.scr);  // (its barriers also order the zeroing below against this block's adds)
-        hist_rows(W, rc, d.hist[tid >> 6], d.runcls, d.queue[tid >> 6]);
+        hist_rows(W, rc, in_size, d.hist[tid >> 6], d.runcls, d.queue[tid >> 6]);
         __syncthreads();
         if (tid < (uint32_t)kSymStride) {
             uint32_t t = 0;
@@ -631,7 +642,7 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) myhist[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            hist_rows(W, rc, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries);
+            hist_rows(W, rc, in_size, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries);
             __builtin_amdgcn_wave_barrier();
             uint32_t bits = 0;
             for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * (d.tab[s].y + run_extra_bits(s));  // (unused symbols: count 0)
@@ -658,7 +669,7 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             if (row_is_dense(W[0], rc[0]))
                 emit_row_dense(W[0], rc[0], d.tab, d.runcls, d.stage, base);
             else
-                emit_row_sparse(W[0], rc[0], d.tab, d.runcls, d.stage, base, queue);
+                emit_row_sparse(W[0], rc[0], in_size, d.tab, d.runcls, d.stage, base, queue);
             rotate_rows(W, rc);
         }
     } else {
