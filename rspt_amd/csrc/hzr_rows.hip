@@ -361,14 +361,29 @@ __device__ __forceinline__ void lane_entries(const uint32_t (&w)[4], const RowCt
     if (rc.last && l == 63u) f(in_size - max(read_lane(incl, 63), rc.rb - rc.zb0), kNoLit);  // the run that reaches the block end
 }
 
+// The entries of a wave's sparse rows, kept for k_encode: a block whose sixteen segments all fit their list is encoded from
+// the lists alone -- no second pass over its 64 KiB of mostly zeros (entry lists).
+constexpr uint32_t kListCap = 512;             // entries per 4 KiB segment
+constexpr uint32_t kListNone = 0xFFFFFFFFu;    // segment info: no list (a dense row, or too many entries)
+struct ListSink {
+    uint32_t* dst;  // this wave's list
+    uint32_t n;     // entries so far, or kListNone
+};
+
 __device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, uint32_t* h, const uint32_t* runcls,
-                                                uint32_t* queue) {
+                                                uint32_t* queue, ListSink& sink) {
     if (rc.valid == 0u) return;
     if (!rc.last && !__ballot((w[0] | w[1] | w[2] | w[3]) != 0u)) return;  // nothing but zeros, and the block goes on: no token ends here
     const uint32_t lits = lane_lits(w);
     bool queued;
     const uint32_t T = sparse_queue(w, rc, in_size, lits, queue, queued);
     if (T == 0) return;
+    if (queued && sink.n != kListNone && sink.n + T <= kListCap) {
+        for (uint32_t c = lane_id(); c < T; c += 64) sink.dst[sink.n + c] = queue[c];
+        sink.n += T;
+    } else {
+        sink.n = kListNone;
+    }
     if (queued) {
         const uint32_t l = lane_id();
         for (uint32_t c = 0; c < T; c += 64) {
@@ -386,6 +401,25 @@ __device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const Ro
     }
 }
 
+// one entry per lane (R zeros, then the literal unless lit == kNoLit; R = 0 and no literal: nothing), in lane order
+__device__ __forceinline__ void emit_entries(uint32_t R, uint32_t lit, const uint2* tab, const uint32_t* runcls, uint32_t* stage, uint32_t& base) {
+    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t rem = R - q * kRunCap;
+    uint64_t rv = 0;
+    uint32_t rl = 0;
+    if (rem) run_token(tab, runcls, rem, rv, rl);
+    const uint2 lc = tab[lit < 256u ? lit : 261u];
+    const uint64_t V = rv | ((uint64_t)lc.x << rl);  // <= 38 + 24 bits
+    const uint32_t vlen = rl + lc.y;
+    const uint32_t caplen = q ? q * (tab[260].y + 14u) : 0u;
+    const uint32_t len = caplen + vlen;
+    const uint32_t inc = wave_scan_add(len);
+    uint32_t pos = base + inc - len;
+    base += read_lane(inc, 63);
+    if (q) pos += emit_run(stage, tab, runcls, pos, q * kRunCap);
+    if (vlen) or_bits64(stage, pos, (uint32_t)V, (uint32_t)(V >> 32));
+}
+
 __device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, const uint2* tab, const uint32_t* runcls,
                                                 uint32_t* stage, uint32_t& base, uint32_t* queue) {
     if (rc.valid == 0u) return;
@@ -399,21 +433,7 @@ __device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const Ro
         for (uint32_t c = 0; c < T; c += 64) {
             uint32_t R, lit;
             queue_entry(queue, rc, c + l, T, R, lit);
-            const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
-            const uint32_t rem = R - q * kRunCap;
-            uint64_t rv = 0;
-            uint32_t rl = 0;
-            if (rem) run_token(tab, runcls, rem, rv, rl);
-            const uint2 lc = tab[lit < 256u ? lit : 261u];
-            const uint64_t V = rv | ((uint64_t)lc.x << rl);  // <= 38 + 24 bits
-            const uint32_t vlen = rl + lc.y;
-            const uint32_t caplen = q ? q * (tab[260].y + 14u) : 0u;
-            const uint32_t len = caplen + vlen;
-            const uint32_t inc = wave_scan_add(len);
-            uint32_t pos = base + inc - len;
-            base += read_lane(inc, 63);
-            if (q) pos += emit_run(stage, tab, runcls, pos, q * kRunCap);
-            if (vlen) or_bits64(stage, pos, (uint32_t)V, (uint32_t)(V >> 32));
+            emit_entries(R, lit, tab, runcls, stage, base);
         }
         __builtin_amdgcn_wave_barrier();
     } else {
@@ -521,13 +541,15 @@ __device__ __forceinline__ void rotate_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4]
 }
 
 __device__ __forceinline__ void hist_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t in_size, uint32_t* myhist, const uint32_t* runcls,
-                                          uint32_t* queue) {
+                                          uint32_t* queue, ListSink& sink) {
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
-        if (row_is_dense(W[0], rc[0]))
+        if (row_is_dense(W[0], rc[0])) {
             hist_row_dense(W[0], rc[0], myhist, runcls);
-        else
-            hist_row_sparse(W[0], rc[0], in_size, myhist, runcls, queue);
+            sink.n = kListNone;
+        } else {
+            hist_row_sparse(W[0], rc[0], in_size, myhist, runcls, queue, sink);
+        }
         rotate_rows(W, rc);
     }
 }
@@ -551,7 +573,8 @@ __shared__ HistLds g_h;
 
 __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
                                                      const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
-                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total) {
+                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total,
+                                                     uint32_t* __restrict__ lists, uint2* __restrict__ listinfo) {
     HistLds& d = g_h;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
     if (threadIdx.x < kRunClsEntries) d.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
@@ -569,7 +592,13 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         uint32_t W[4][4];
         RowCtx rc[4];
         load_block_rows(in, in_size, segmask, W, rc, d.scr);  // (its barriers also order the zeroing below against this block's adds)
-        hist_rows(W, rc, in_size, d.hist[tid >> 6], d.runcls, d.queue[tid >> 6]);
+        {
+            const uint32_t wv = tid >> 6;
+            ListSink sink{lists + ((size_t)hb * kEncWaves + wv) * kListCap, 0u};
+            const uint32_t before = rc[0].rb - rc[0].zb0;  // position behind the last literal in front of this wave's segment
+            hist_rows(W, rc, in_size, d.hist[wv], d.runcls, d.queue[wv], sink);
+            if ((tid & 63u) == 0) listinfo[(size_t)hb * kEncWaves + wv] = make_uint2(sink.n, before);
+        }
         __syncthreads();
         if (tid < (uint32_t)kSymStride) {
             uint32_t t = 0;
@@ -607,7 +636,8 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
                                                   const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                   const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                   const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                                  const uint32_t* __restrict__ segbase) {
+                                                  const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ lists,
+                                                  const uint2* __restrict__ listinfo) {
     EncRowsLds& d = g_e;
     const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
     // three independent loads in one round trip (their addresses depend on the block index only)
@@ -615,7 +645,8 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
     const uint64_t off = out_off[hb];
     const uint32_t segmask = nzflag[hb];
     if (off == ~0ull) return;  // stream does not fit dst_stride (flagged in sizes[b])
-    const uint32_t tid = thread_id(), w = tid >> 6, l = tid & 63u;
+    const uint32_t tid = thread_id(), l = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     uint8_t* o = dst + (size_t)b * dst_stride + off;
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
     uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
@@ -632,6 +663,31 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             d.tab[tid] = make_uint2(c & 0x00FFFFFFu, c >> 24);
         }
         const bool own_bits = first_base == 0xFFFFFFFFu;  // (block-uniform)
+        // Did k_hist leave the entry lists of all sixteen segments?  Then the block is encoded from them alone.
+        const uint2 li = listinfo[(size_t)hb * kEncWaves + (l & 15u)];
+        const bool from_lists = !own_bits && !__ballot(li.x == kListNone);
+        if (from_lists) {
+            for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
+            __syncthreads();  // the table and the zeroed image are in place
+            const uint32_t twords = (m.tree_bits + 31u) >> 5;
+            if (tid < twords) atomicOr(&d.stage[1u + tid], tdesc[(size_t)hb * kTdescWords + tid]);
+            const uint32_t n = read_lane(li.x, w), before0 = read_lane(li.y, w);
+            const uint32_t* list = lists + ((size_t)hb * kEncWaves + w) * kListCap;
+            const bool wipe = block_is_wiped(m);
+            for (uint32_t c = 0; c < n; c += 64) {
+                const uint32_t kq = c + l;
+                uint32_t R = 0, lit = kNoLit;
+                if (kq < n) {
+                    const uint32_t e = list[kq];
+                    const uint32_t before = kq ? (list[kq - 1u] >> 9) + 1u : before0;
+                    lit = e & 0x1FFu;
+                    R = (e >> 9) - before;
+                    // clean-block invariant: a light block leaves zeros behind (the granule of every literal)
+                    if (wipe && lit < 256u) *reinterpret_cast<uint4*>(in + ((e >> 9) & ~15u)) = make_uint4(0, 0, 0, 0);
+                }
+                emit_entries(R, lit, d.tab, d.runcls, d.stage, base);
+            }
+        } else {
         if (!own_bits)
             for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
         load_block_rows(in, in_size, segmask, W, rc, d.scr);  // barriers inside publish the table and the zeroed image
@@ -642,7 +698,8 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) myhist[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            hist_rows(W, rc, in_size, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries);
+            ListSink none{nullptr, kListNone};
+            hist_rows(W, rc, in_size, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries, none);
             __builtin_amdgcn_wave_barrier();
             uint32_t bits = 0;
             for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * (d.tab[s].y + run_extra_bits(s));  // (unused symbols: count 0)
@@ -672,6 +729,7 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
                 emit_row_sparse(W[0], rc[0], in_size, d.tab, d.runcls, d.stage, base, queue);
             rotate_rows(W, rc);
         }
+        }  // (rows path)
     } else {
         // PlainCopy (hzr_encode.c:307-339): the payload is the raw block; words past it stay defined (zero)
         for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
@@ -752,7 +810,8 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
                                                           const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                           WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list,
-                                                          const uint32_t* __restrict__ segbase) {
+                                                          const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ lists,
+                                                          const uint2* __restrict__ listinfo) {
     (&g_e.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     const uint32_t n_big = wq->n_big;
@@ -764,7 +823,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
         __syncthreads();
         const uint32_t i = g_e.slot;
         if (i >= n_big) break;
-        encode_block_rows(big_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, segbase);
+        encode_block_rows(big_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, segbase, lists, listinfo);
     }
 }
 

@@ -131,6 +131,8 @@ struct rspt_hip_packer {
     uint32_t* hist = nullptr;      // [cap*4*nblk][264]
     uint32_t* seghist = nullptr;   // [cap*4*nblk][16][264] u16: tokens ending in each 4 KiB segment (k_hist -> k_tree)
     uint32_t* segbase = nullptr;   // [cap*4*nblk][16] stream bit at which each segment's tokens start (k_tree -> k_encode)
+    uint32_t* lists = nullptr;     // [cap*4*nblk][16][kListCap] (position << 9 | value) entries of the sparse segments (k_hist -> k_encode)
+    uint2* listinfo = nullptr;     // [cap*4*nblk][16] {entries or kListNone, position behind the last literal before the segment}
     uint32_t* cw = nullptr;        // [cap*4*nblk][264] code | length << 24 per symbol
     uint32_t* tdesc = nullptr;     // [..][92]
     BlockMeta* meta = nullptr;     // [..]
@@ -359,7 +361,10 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->hist);
     hipFree(p->seghist);
     hipFree(p->segbase);
-    p->seghist = p->segbase = nullptr;
+    hipFree(p->lists);
+    hipFree(p->listinfo);
+    p->seghist = p->segbase = p->lists = nullptr;
+    p->listinfo = nullptr;
     hipFree(p->cw);
     hipFree(p->tdesc);
     hipFree(p->meta);
@@ -642,6 +647,8 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->cw, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->seghist, nhb * (size_t)kSegHistStride * sizeof(uint16_t)) == hipSuccess;
     ok &= hipMalloc(&p->segbase, nhb * (size_t)kEncWaves * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->lists, nhb * (size_t)kEncWaves * kListCap * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->listinfo, nhb * (size_t)kEncWaves * sizeof(uint2)) == hipSuccess;
     ok &= hipMalloc(&p->tdesc, nhb * kTdescWords * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->meta, nhb * sizeof(BlockMeta)) == hipSuccess;
     ok &= hipMalloc(&p->out_off, nhb * sizeof(uint64_t)) == hipSuccess;
@@ -753,7 +760,8 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_HIST, st);
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
     const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
-    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->work_ctr, nhb);
+    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->work_ctr, nhb,
+                       p->lists, p->listinfo);
 
     stamp(p, ST_TREE, st);
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
@@ -776,7 +784,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         HIPCHK(p, hipEventRecord(p->ev_join, p->side));
     }
     hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
-                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase);
+                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo);
     stamp(p, ST_ENCODE_SMALL, st);
     HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
