@@ -466,11 +466,9 @@ __device__ __forceinline__ bool row_is_dense(const uint32_t (&w)[4], const RowCt
 // ===========================================================================
 // the block in registers: four granules per lane, and what every row has to know about its surroundings
 // ===========================================================================
-// scr: kEncWaves words of LDS.  Two barriers inside (they also publish whatever the caller wrote to LDS before).
-__device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t (&W)[4][4],
-                                                RowCtx (&rc)[4], uint32_t* scr) {
-    const uint32_t tid = thread_id(), l = tid & 63u;
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (wave-uniform: keeps the row contexts in scalar registers)
+// The loads alone: issued early (for the NEXT block while the current one is in its last phases), consumed by chain_block_rows.
+__device__ __forceinline__ void issue_block_loads(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t (&W)[4][4]) {
+    const uint32_t tid = thread_id(), l = tid & 63u, w = tid >> 6;
     const bool seg_nz = (segmask >> w) & 1u;  // a wave whose 4 KiB segment is all zero (front-end non-zero map) does not read HBM at all
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -481,6 +479,16 @@ __device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, 
         W[r][1] = v.y;
         W[r][2] = v.z;
         W[r][3] = v.w;
+    }
+}
+
+// scr: kEncWaves words of LDS.  Two barriers inside (they also publish whatever the caller wrote to LDS before).
+__device__ __forceinline__ void chain_block_rows(uint32_t in_size, uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t* scr) {
+    const uint32_t tid = thread_id(), l = tid & 63u;
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // (wave-uniform: keeps the row contexts in scalar registers)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t pos = w * 4096u + r * 1024u + l * 16u;
         if (pos + 16u > in_size && pos < in_size) {  // the block's last, partial granule: bytes behind it read as zero
             const uint32_t nv = in_size - pos;
 #pragma unroll
@@ -519,6 +527,12 @@ __device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, 
         c = max(c, behind[r]);
     }
     __syncthreads();  // scr may be reused by the caller
+}
+
+__device__ __forceinline__ void load_block_rows(const uint8_t* __restrict__ in, uint32_t in_size, uint32_t segmask, uint32_t (&W)[4][4],
+                                                RowCtx (&rc)[4], uint32_t* scr) {
+    issue_block_loads(in, in_size, segmask, W);
+    chain_block_rows(in_size, W, rc, scr);
 }
 
 // rotate the rows through W[0] / rc[0]: the row bodies exist once in the instruction stream; four turns put everything back
@@ -571,33 +585,75 @@ struct HistLds {
 };
 __shared__ HistLds g_h;
 
-__global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nbuse,
-                                                     const uint32_t* __restrict__ nzflag, uint32_t* __restrict__ hist,
-                                                     uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter, uint32_t total,
+// The blocks k_hist takes (a plane in use, more than kSmallSegments non-zero segments), in any order: work_ctr[2] = count.
+__global__ __launch_bounds__(256) void k_histlist(const uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, Geom g, uint32_t nhb_total,
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    const uint32_t v = blockIdx.x * 256u + threadIdx.x, l = lane_id();
+    bool take = false;
+    uint32_t hb = 0;
+    if (v < nhb_total) {
+        // plane fastest: consecutive list entries alternate between the dense plane and the light ones (a persistent
+        // workgroup that takes them in turn keeps a CU's two workgroups in different phases more often)
+        const uint32_t k = v % kMaxPlanes, j = (v / kMaxPlanes) % g.nblk, b = v / (kMaxPlanes * g.nblk);
+        hb = hb_index(g, b, k, j);
+        take = k < nbuse[b] && (uint32_t)__popc(nzflag[hb]) > kSmallSegments;
+    }
+    const unsigned long long m = __ballot(take);
+    if (!m) return;
+    uint32_t base = 0;
+    if (l == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = read_lane(base, (uint32_t)__builtin_ctzll(m));
+    if (take) list[base + (uint32_t)__popcll(m & ((1ull << l) - 1ull))] = hb;
+}
+
+__global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
+                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ seghist, uint32_t* __restrict__ counter,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ count,
                                                      uint32_t* __restrict__ lists, uint2* __restrict__ listinfo) {
     HistLds& d = g_h;
     for (uint32_t i = threadIdx.x; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
     if (threadIdx.x < kRunClsEntries) d.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
-    WorkItem wi;
-    for (uint32_t pass = 0; next_work(counter, total, g, &d.slot, wi, pass); ++pass) {
+    const uint32_t n = *count;
+    // Persistent, software-pipelined: the first block is static, the rest come from a counter whose fetch-add is issued
+    // one block ahead; the NEXT block's granules are loaded as soon as the current block's rows are done, so that their
+    // latency falls into the reduction (and the wait for the slowest wave) instead of the start of the next pass.
+    auto block_of = [&](uint32_t hb, const uint8_t*& in, uint32_t& in_size) {
+        const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
+        in_size = min(kHzrBlock, g.N - j * kHzrBlock);
+        in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
+    };
+    uint32_t cur = blockIdx.x;
+    uint32_t W[4][4];
+    uint32_t hb = 0, in_size = 0;
+    if (cur < n) {
+        hb = list[cur];
+        const uint8_t* in;
+        block_of(hb, in, in_size);
+        issue_block_loads(in, in_size, nzflag[hb], W);
+    }
+    while (cur < n) {
         const uint32_t tid = thread_id();
-        const uint32_t j = wi.j, k = wi.k, b = wi.b;
-        const uint32_t hb = hb_index(g, b, k, j);
-        const uint32_t nbu = nbuse[b];
-        const uint32_t segmask = nzflag[hb];  // (independent of nbu: one round trip)
-        if (k >= nbu) continue;
-        if ((uint32_t)__popc(segmask) <= kSmallSegments) continue;  // all zero (k_tree: Fill(0)) or small (k_tree takes the histogram itself)
-        const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-        const uint8_t* in = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;
-        uint32_t W[4][4];
+        if (tid == 0) d.slot = gridDim.x + atomicAdd(counter, 1u);  // (read behind the chain's barriers)
         RowCtx rc[4];
-        load_block_rows(in, in_size, segmask, W, rc, d.scr);  // (its barriers also order the zeroing below against this block's adds)
+        chain_block_rows(in_size, W, rc, d.scr);  // (its barriers also order the zeroing below against this block's adds)
+        const uint32_t nxt = d.slot;
+        uint32_t hbn = 0, segn = 0;
+        if (nxt < n) {
+            hbn = list[nxt];
+            segn = nzflag[hbn];
+        }
         {
             const uint32_t wv = tid >> 6;
             ListSink sink{lists + ((size_t)hb * kEncWaves + wv) * kListCap, 0u};
             const uint32_t before = rc[0].rb - rc[0].zb0;  // position behind the last literal in front of this wave's segment
             hist_rows(W, rc, in_size, d.hist[wv], d.runcls, d.queue[wv], sink);
             if ((tid & 63u) == 0) listinfo[(size_t)hb * kEncWaves + wv] = make_uint2(sink.n, before);
+        }
+        uint32_t in_size_n = 0;
+        if (nxt < n) {  // the rows are done: their registers take the next block
+            const uint8_t* in_n;
+            block_of(hbn, in_n, in_size_n);
+            issue_block_loads(in_n, in_size_n, segn, W);
         }
         __syncthreads();
         if (tid < (uint32_t)kSymStride) {
@@ -613,12 +669,27 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         }
         __syncthreads();  // everyone has read the histograms
         for (uint32_t i = tid; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
+        cur = nxt;
+        hb = hbn;
+        in_size = in_size_n;
     }
 }
 
 // ===========================================================================
 // k_encode
 // ===========================================================================
+// RSPT_DIAG builds (never the product library): thread 0 stores s_memtime at the phase seams of the first 6000 list entries
+#ifdef RSPT_DIAG
+#define ENC_STAMP(i)                                                                                              \
+    do {                                                                                                          \
+        if (stamps && threadIdx.x == 0 && list_pos < 6000u) stamps[list_pos * 16u + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define ENC_STAMP(i) \
+    do {             \
+    } while (0)
+#endif
+
 struct EncRowsLds {
     uint2 tab[kSymStride];  // {code, length} per lookup index; 261..263 = {0, 0} (a byte that ends no token)
     uint32_t crc[4][256];   // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
@@ -637,8 +708,9 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
                                                   const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                   const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                   const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ lists,
-                                                  const uint2* __restrict__ listinfo) {
+                                                  const uint2* __restrict__ listinfo, unsigned long long* __restrict__ stamps, uint32_t list_pos) {
     EncRowsLds& d = g_e;
+    ENC_STAMP(0);
     const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);
     // three independent loads in one round trip (their addresses depend on the block index only)
     const BlockMeta m = meta[hb];
@@ -691,6 +763,7 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
         if (!own_bits)
             for (uint32_t i = tid; i < zwords; i += kEncThreads) d.stage[i] = 0;
         load_block_rows(in, in_size, segmask, W, rc, d.scr);  // barriers inside publish the table and the zeroed image
+        ENC_STAMP(1);
         if (own_bits) {
             // the block's histogram was taken by k_tree in one piece (few non-zero segments, but too big for
             // k_encode_small): count this wave's tokens here -- histogram in the (still unused) image, times the code lengths
@@ -744,7 +817,9 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
         }
     }
     if (tid == 0) atomicOr(&d.stage[0], cc->prefix);  // X (word 0 was zeroed above)
+    ENC_STAMP(2);
     __syncthreads();
+    ENC_STAMP(3);
 
     // ---- CRC-32C: V = X || payload (Lv = L + 4 bytes from image byte 0) as 4-byte virtual words counted from its END;
     //      lane tid owns the words tid, tid + 1024, ... (consecutive lanes read consecutive LDS words), Horner over its
@@ -781,6 +856,7 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             d.crc_out = ~t;
         }
         __syncthreads();
+        ENC_STAMP(4);
     }
 
     // ---- block header + payload to the stream (hzr_encode.c:475-481) --------
@@ -803,6 +879,10 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
     uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
     // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
     for (uint32_t i = tid; i < nd; i += kEncThreads) pw[i] = __builtin_amdgcn_alignbyte(d.stage[i + 2], d.stage[i + 1], head);
+    ENC_STAMP(5);
+#ifdef RSPT_DIAG
+    if (stamps && threadIdx.x == 0 && list_pos < 6000u) stamps[list_pos * 16u + 6u] = ((unsigned long long)m.mode << 32) | L;
+#endif
 }
 
 __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ nzflag,
@@ -811,7 +891,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                           WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list,
                                                           const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ lists,
-                                                          const uint2* __restrict__ listinfo) {
+                                                          const uint2* __restrict__ listinfo, unsigned long long* __restrict__ stamps) {
     (&g_e.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     const uint32_t n_big = wq->n_big;
@@ -823,7 +903,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
         __syncthreads();
         const uint32_t i = g_e.slot;
         if (i >= n_big) break;
-        encode_block_rows(big_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, segbase, lists, listinfo);
+        encode_block_rows(big_list[i], planes, g, nzflag, meta, cw, tdesc, out_off, cc, dst, dst_stride, segbase, lists, listinfo, stamps, i);
     }
 }
 

@@ -760,8 +760,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_HIST, st);
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
     const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
-    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nbuse, p->nzflag, p->hist, p->seghist, p->work_ctr, nhb,
-                       p->lists, p->listinfo);
+    // (the list of k_hist's blocks sits in big_list until k_layout refills that array for k_encode; its count in work_ctr[2])
+    hipLaunchKernelGGL(k_histlist, dim3((nhb + 255) / 256), dim3(256), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, p->work_ctr + 2);
+    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->hist, p->seghist, p->work_ctr, p->big_list,
+                       p->work_ctr + 2, p->lists, p->listinfo);
 
     stamp(p, ST_TREE, st);
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
@@ -784,7 +786,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         HIPCHK(p, hipEventRecord(p->ev_join, p->side));
     }
     hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
-                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo);
+                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo, p->stamps);
     stamp(p, ST_ENCODE_SMALL, st);
     HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
