@@ -97,6 +97,20 @@ int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb);
  * form: bit 63 of d_consumed[b]).  Off by default. */
 int rspt_hip_set_verify(rspt_hip_packer* p, int on);
 
+/* Byte order of the samples (default 0 = little-endian, what every reference packer passes: signal_packer_xdelta_hzr.cpp:54).
+ * With big_endian != 0 compress reads samples whose bytes are reversed -- convert_native_to_i32(..., reverse_byte_order =
+ * true), lib_signalpacker/utils.cpp:127-137,145-154,162-170 -- and decompress writes them that way (convert_i32_to_native,
+ * utils.cpp:57-64,77-85,97-104): a 24-bit ADC feed in network byte order needs no host pass.  The streams are those of the
+ * byte-reversed (little-endian) block. */
+int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian);
+
+/* Page-locked host memory for the host-pointer entry points: with src / dst in such buffers rspt_hip_compress and
+ * rspt_hip_decompress move their data by DMA at link rate instead of through the runtime's pageable staging copies
+ * (the acquisition front end of the reference, lib_ring_buffer/ring_buffers.h:150-203 io_buffer, would allocate its
+ * slots here).  NULL on failure. */
+void* rspt_hip_host_alloc(size_t bytes);
+void rspt_hip_host_free(void* p);
+
 /* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
 
 /* Grow the workspace so that up to max_blocks blocks can go through one
@@ -147,6 +161,19 @@ int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_st
  * truncated or corrupt container flags its streams (bit 63 of d_consumed[b]) instead of reading out of bounds. */
 int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t packed_len, size_t nblocks, void* d_dst, uint64_t* d_consumed,
                                    void* stream);
+
+/* ---- optional stage in front of compress: the reference's IIR pre-filter ---------------------------------------
+ * Replaces the filter step of the reference's own pipeline (lib_rspt_test/rspt_test.cpp:116-136): i_filter::new_iir
+ * (n, d, nr_coefficients), init_history_values(first sample of the channel, init_nr_samples), filter_opt on every sample
+ * (lib_rspt/lib_filter/iir_filter.cpp:46-116), result truncated to int32 and stored back in the native sample width --
+ * nblocks device-resident blocks (interleaved native layout, as for compress), IN PLACE, bit-identical with the reference.
+ *   n, d            host arrays of nr_coefficients doubles (2..5): feedback (n[0] unused) and feed-forward coefficients
+ *   per_channel     0: one filter object for all channels of a block, its state running on from channel to channel, as
+ *                      in the reference's harness (the channels of a block are then a serial chain: one thread per block);
+ *                   1: a fresh filter per channel (one i_filter per channel): one thread per channel
+ * Asynchronous on `stream`. */
+int rspt_hip_iir_prefilter_batch_dev(rspt_hip_packer* p, void* d_buf, size_t nblocks, const double* n, const double* d, size_t nr_coefficients,
+                                     int init_nr_samples, int per_channel, void* stream);
 
 /* The handle's own (non-blocking) stream, as a hipStream_t. */
 void* rspt_hip_stream(rspt_hip_packer* p);

@@ -47,4 +47,9 @@ public:
     static void delete_lala(i_signal_packer* instance);
 };
 
+/* GPU placement of the packers the calling thread creates from now on (additive; the reference's factories have no such
+ * argument): -1 = the RSPT_HIP_DEVICE environment variable, else device 0.  Returns the previous setting.  One packer per
+ * host thread and one thread per GPU is how a C++ caller shards independent blocks over the devices of a node. */
+extern "C" int rspt_cxx_set_device(int device);
+
 #endif /* RSPT_AMD_SIGNAL_PACKER_H_ */

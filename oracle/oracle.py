@@ -30,7 +30,10 @@ def build(force=False):
         os.path.getmtime(ORACLE_SO) < os.path.getmtime(os.path.join(_HERE, "rspt_oracle.c"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "librspt_oracle.so"], stdout=subprocess.DEVNULL)
-    if os.path.exists("/root/reference/lib_rspt/signal_packer.h") and not os.path.exists(REF_SO):
+    if os.path.exists("/root/reference/lib_rspt/signal_packer.h") and (
+        force or not os.path.exists(REF_SO)
+        or os.path.getmtime(REF_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("ref_shim.cpp", "Makefile"))
+    ):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
@@ -150,6 +153,18 @@ class Oracle(_Lib):
         L.orc_native_to_i32.argtypes = [C.POINTER(C.c_int32), _u8p, C.c_size_t, C.c_size_t, C.c_size_t]
         L.orc_fwht.restype, L.orc_fwht.argtypes = None, [C.POINTER(C.c_int32), C.c_size_t]
         L.orc_average_32.restype, L.orc_average_32.argtypes = C.c_int32, [C.POINTER(C.c_int32), C.c_size_t]
+        L.orc_iir_prefilter_native.restype = C.c_int
+        L.orc_iir_prefilter_native.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int, C.c_int]
+
+    def iir_prefilter(self, native, bps, nch, ns, n, d, init_nr_samples=2000, shared_state=True):
+        """the reference's pre-filter step (rspt_test.cpp:116-136): interleaved native block -> filtered native block"""
+        a = _as_u8(native).copy()
+        nn, dd = np.ascontiguousarray(n, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64)
+        rc = self.lib.orc_iir_prefilter_native(_ptr(a), bps, nch, ns, nn.ctypes.data_as(C.POINTER(C.c_double)), dd.ctypes.data_as(C.POINTER(C.c_double)),
+                                               nn.size, init_nr_samples, int(bool(shared_state)))
+        if rc != 0:
+            raise ValueError("orc_iir_prefilter_native rc=%d" % rc)
+        return a.tobytes()
 
     # ---- dct beyond the dense table (ns > 8192): fp64 restatement -----------------------------
     # Same definition as signal_packer_dct.cpp:76-100 with the cosines in fp64 instead of the float32
@@ -298,6 +313,34 @@ class Ref(_Lib):
         L = self.lib
         L.ref_hzr_decode.restype, L.ref_hzr_decode.argtypes = C.c_int, [_u8p, C.c_size_t, _u8p, C.c_size_t]
         L.ref_hzr_verify.restype, L.ref_hzr_verify.argtypes = C.c_int, [_u8p, C.c_size_t, _szp]
+        L.ref_iir_prefilter_native.restype = C.c_int
+        L.ref_iir_prefilter_native.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]
+        L.ref_native_to_i32.restype = None
+        L.ref_native_to_i32.argtypes = [C.POINTER(C.c_int32), _u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+        L.ref_i32_to_native.restype = None
+        L.ref_i32_to_native.argtypes = [_u8p, C.POINTER(C.c_int32), C.c_size_t, C.c_size_t, C.c_size_t, C.c_int]
+
+    def iir_prefilter(self, native, bps, nch, ns, n, d, init_nr_samples=2000):
+        a = np.zeros(_as_u8(native).size + 8, dtype=np.uint8)  # (the reference over-reads up to 3 bytes for bps < 4)
+        a[: _as_u8(native).size] = _as_u8(native)
+        nn, dd = np.ascontiguousarray(n, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64)
+        self.lib.ref_iir_prefilter_native(_ptr(a), bps, nch, ns, nn.ctypes.data_as(C.POINTER(C.c_double)), dd.ctypes.data_as(C.POINTER(C.c_double)),
+                                          nn.size, init_nr_samples)
+        return a[: bps * nch * ns].tobytes()
+
+    def native_to_i32(self, native, ns, nch, bps, reverse_byte_order=False):
+        a = np.zeros(_as_u8(native).size + 8, dtype=np.uint8)
+        a[: _as_u8(native).size] = _as_u8(native)
+        out = np.zeros((nch, ns), dtype=np.int32)
+        self.lib.ref_native_to_i32(out.ctypes.data_as(C.POINTER(C.c_int32)), _ptr(a), ns, nch, bps, int(reverse_byte_order))
+        return out
+
+    def i32_to_native(self, planar, bps, reverse_byte_order=False):
+        pl = np.ascontiguousarray(planar, dtype=np.int32)
+        nch, ns = pl.shape
+        out = np.zeros(bps * nch * ns + 8, dtype=np.uint8)
+        self.lib.ref_i32_to_native(_ptr(out), pl.ctypes.data_as(C.POINTER(C.c_int32)), ns, nch, bps, int(reverse_byte_order))
+        return out[: bps * nch * ns].tobytes()
 
     def hzr_decode(self, stream, out_size):
         s = _as_u8(stream)

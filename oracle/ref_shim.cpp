@@ -13,12 +13,16 @@
 #include <cstddef>
 #include <cstdint>
 #include <iostream>
+#include <vector>
 
 #include "signal_packer.h" /* -I$(REF)/lib_rspt ; the header has no includes of its own */
 
 extern "C" {
 #include "lib_hzr/libhzr.h"
 }
+using namespace std;       /* filter.h names vector<double> unqualified */
+#include "filter.h"        /* i_filter (lib_rspt/filter.h:24-89) */
+#include "lib_signalpacker/utils.h" /* convert_native_to_i32 / convert_i32_to_native */
 
 namespace {
 struct ref_handle {
@@ -79,6 +83,36 @@ int ref_hzr_decode(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_ca
 
 int ref_hzr_verify(const uint8_t* in, size_t in_len, size_t* decoded) {
     return hzr_verify(in, in_len, decoded) == HZR_OK;
+}
+
+
+/* The reference's pre-filter step, driven exactly as its test harness does (lib_rspt_test/rspt_test.cpp:116-136):
+ * one i_filter for all channels, init_history_values(first sample, init_nr_samples), filter_opt per sample. */
+int ref_iir_prefilter_native(uint8_t* native, size_t bps, size_t nch, size_t ns, const double* n, const double* d, size_t nc, int init_nr_samples) {
+    std::vector<int32_t> flat(nch * ns);
+    std::vector<int32_t*> rows(nch);
+    for (size_t c = 0; c < nch; ++c) rows[c] = flat.data() + c * ns;
+    convert_native_to_i32(rows.data(), native, (int)ns, (int)nch, (int)bps, false);
+    i_filter* f = i_filter::new_iir(n, d, nc);
+    for (size_t j = 0; j < nch; ++j) {
+        f->init_history_values(rows[j][0], init_nr_samples);
+        for (size_t i = 0; i < ns; ++i) rows[j][i] = f->filter_opt(rows[j][i]);
+    }
+    i_filter::delete_iir(f);
+    convert_i32_to_native(native, rows.data(), (int)ns, (int)nch, (int)bps, false);
+    return 0;
+}
+
+/* convert_native_to_i32 with the byte order the caller picks (utils.cpp:123-191): fixtures for big-endian ingest */
+void ref_native_to_i32(int32_t* planar, const uint8_t* native, size_t ns, size_t nch, size_t bps, int reverse_byte_order) {
+    std::vector<int32_t*> rows(nch);
+    for (size_t c = 0; c < nch; ++c) rows[c] = planar + c * ns;
+    convert_native_to_i32(rows.data(), native, (int)ns, (int)nch, (int)bps, reverse_byte_order != 0);
+}
+void ref_i32_to_native(uint8_t* native, const int32_t* planar, size_t ns, size_t nch, size_t bps, int reverse_byte_order) {
+    std::vector<int32_t*> rows(nch);
+    for (size_t c = 0; c < nch; ++c) rows[c] = const_cast<int32_t*>(planar) + c * ns;
+    convert_i32_to_native(native, rows.data(), (int)ns, (int)nch, (int)bps, reverse_byte_order != 0);
 }
 
 }  /* extern "C" */

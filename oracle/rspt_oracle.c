@@ -971,3 +971,77 @@ double orc_prdn(const uint8_t* orig_native, const uint8_t* dec_native, size_t ns
     free(d);
     return sqrt(mse / ref) * 100.0;
 }
+
+
+/* ===========================================================================
+ * IIR pre-filter: the step in front of the packers in the reference's own pipeline
+ * (lib_rspt_test/rspt_test.cpp:116-136), lib_rspt/lib_filter/iir_filter.cpp:46-116.
+ * Double arithmetic in exactly the reference's order of operations (build with
+ * -ffp-contract=off: no fused multiply-add, as in the reference's x86-64 build).
+ * ===========================================================================*/
+typedef struct {
+    double x[5], y[5], n[5], d[5];
+    size_t nc;
+} orc_iir;
+
+static void iir_shift(orc_iir* f, double x) { /* iir_filter.cpp:66-71, 81-86 */
+    for (size_t i = f->nc - 1; i > 0; --i) {
+        f->x[i] = f->x[i - 1];
+        f->y[i] = f->y[i - 1];
+    }
+    f->x[0] = x;
+}
+
+static double iir_filter(orc_iir* f, double x) { /* i_filter::filter, iir_filter.cpp:64-77: terms added one by one, feed-forward and feedback interleaved */
+    iir_shift(f, x);
+    double acc = f->d[0] * f->x[0];
+    for (size_t i = 1; i < f->nc; ++i) {
+        acc += f->d[i] * f->x[i];
+        acc -= f->n[i] * f->y[i];
+    }
+    f->y[0] = acc;
+    return acc;
+}
+
+static double iir_filter_opt(orc_iir* f, double x) { /* i_filter::filter_opt, iir_filter.cpp:79-104 with :23-41: one expression, left to right */
+    iir_shift(f, x);
+    const double *d = f->d, *n = f->n, *xz = f->x;
+    double* yz = f->y;
+    switch (f->nc) {
+        case 5: yz[0] = d[0] * xz[0] + d[1] * xz[1] + d[2] * xz[2] + d[3] * xz[3] + d[4] * xz[4] - n[1] * yz[1] - n[2] * yz[2] - n[3] * yz[3] - n[4] * yz[4]; break;
+        case 4: yz[0] = d[0] * xz[0] + d[1] * xz[1] + d[2] * xz[2] + d[3] * xz[3] - n[1] * yz[1] - n[2] * yz[2] - n[3] * yz[3]; break;
+        case 3: yz[0] = d[0] * xz[0] + d[1] * xz[1] + d[2] * xz[2] - n[1] * yz[1] - n[2] * yz[2]; break;
+        case 2: yz[0] = d[0] * xz[0] + d[1] * xz[1] - n[1] * yz[1]; break;
+        default: break; /* (the reference leaves y[0] as shifted: not a filter; callers pass 2..5) */
+    }
+    return yz[0];
+}
+
+int orc_iir_prefilter_native(uint8_t* native, size_t bps, size_t nch, size_t ns, const double* n, const double* d, size_t nc, int init_nr_samples,
+                             int shared_state) {
+    /* rspt_test.cpp:118-135: native -> [nch][ns] int32, ONE filter object for all channels (its state runs on from
+     * channel to channel: init_history_values feeds 4*nr_samples copies of the channel's first sample through
+     * filter(), which damps the old state but does not erase it), filter_opt per sample, result truncated to int32,
+     * back to native.  shared_state = 0: a fresh filter per channel (what the GPU's channel-parallel mode computes). */
+    if (nc < 2 || nc > 5 || bps < 1 || bps > 4) return -1;
+    int32_t* planar = (int32_t*)malloc(sizeof(int32_t) * nch * ns);
+    if (!planar) return -2;
+    orc_native_to_i32(planar, native, ns, nch, bps);
+    orc_iir f;
+    memset(&f, 0, sizeof f);
+    f.nc = nc;
+    memcpy(f.n, n, nc * sizeof(double));
+    memcpy(f.d, d, nc * sizeof(double));
+    for (size_t c = 0; c < nch; ++c) {
+        int32_t* row = planar + c * ns;
+        if (!shared_state) {
+            memset(f.x, 0, sizeof f.x);
+            memset(f.y, 0, sizeof f.y);
+        }
+        for (int i = 0; i < 4 * init_nr_samples; ++i) iir_filter(&f, (double)row[0]); /* init_history_values :106-110 */
+        for (size_t s = 0; s < ns; ++s) row[s] = (int32_t)iir_filter_opt(&f, (double)row[s]);
+    }
+    orc_i32_to_native(native, planar, ns, nch, bps);
+    free(planar);
+    return 0;
+}

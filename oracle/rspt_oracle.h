@@ -115,6 +115,12 @@ double orc_prdn(const uint8_t* orig_native, const uint8_t* dec_native, size_t ns
 /* 32-bit FNV-1a, the hash SURVEY.md section 6 quotes for golden streams. */
 uint32_t orc_fnv1a(const void* data, size_t len);
 
+/* IIR pre-filter of an interleaved native block, in place: the reference's pipeline step in front of the packers
+ * (lib_rspt_test/rspt_test.cpp:116-136 with lib_rspt/lib_filter/iir_filter.cpp:46-116).  nc = 2..5 coefficients,
+ * n = feedback (n[0] unused), d = feed-forward.  shared_state != 0: one filter object for all channels, as there. */
+int orc_iir_prefilter_native(uint8_t* native, size_t bps, size_t nch, size_t ns, const double* n, const double* d, size_t nc, int init_nr_samples,
+                             int shared_state);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
-    "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read",
+    "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
 ]
 
 _u8p = C.POINTER(C.c_uint8)
@@ -92,11 +92,18 @@ def lib():
     L.rspt_hip_stage_name.restype, L.rspt_hip_stage_name.argtypes = C.c_char_p, [C.c_void_p, C.c_int]
     L.rspt_hip_stage_times.restype, L.rspt_hip_stage_times.argtypes = C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]
     L.rspt_hip_debug_read.restype, L.rspt_hip_debug_read.argtypes = C.c_longlong, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.rspt_hip_set_byte_order.restype, L.rspt_hip_set_byte_order.argtypes = C.c_int, [C.c_void_p, C.c_int]
+    L.rspt_hip_host_alloc.restype, L.rspt_hip_host_alloc.argtypes = C.c_void_p, [C.c_size_t]
+    L.rspt_hip_host_free.restype, L.rspt_hip_host_free.argtypes = None, [C.c_void_p]
+    L.rspt_hip_iir_prefilter_batch_dev.restype = C.c_int
+    L.rspt_hip_iir_prefilter_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int,
+                                                   C.c_int, C.c_void_p]
     # the C++ factories behind the same library (include/signal_packer.h), via their C shim
     L.rspt_cxx_new.restype, L.rspt_cxx_new.argtypes = C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
     L.rspt_cxx_delete.restype, L.rspt_cxx_delete.argtypes = None, [C.c_int, C.c_void_p]
     L.rspt_cxx_compress.restype, L.rspt_cxx_compress.argtypes = None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _szp]
     L.rspt_cxx_decompress.restype, L.rspt_cxx_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
+    L.rspt_cxx_set_device.restype, L.rspt_cxx_set_device.argtypes = C.c_int, [C.c_int]
     _lib = L
     return L
 
@@ -146,6 +153,17 @@ class SignalPacker:
         self._check("rspt_hip_compress", self._L.rspt_hip_compress(self._h, a.ctypes.data, out.ctypes.data, cap, C.byref(n)))
         return out[: n.value].tobytes()
 
+    def compress_into(self, src, out):
+        """host buffers as they are (numpy uint8 arrays, e.g. from host_alloc): -> stream length"""
+        n = C.c_size_t(0)
+        self._check("rspt_hip_compress", self._L.rspt_hip_compress(self._h, src.ctypes.data, out.ctypes.data, out.size, C.byref(n)))
+        return n.value
+
+    def decompress_into(self, stream, out):
+        n = C.c_size_t(0)
+        self._check("rspt_hip_decompress", self._L.rspt_hip_decompress(self._h, stream.ctypes.data, C.byref(n), out.ctypes.data))
+        return n.value
+
     def decompress(self, stream):
         s = _as_u8(stream)
         out = np.empty(self.block_bytes, dtype=np.uint8)
@@ -159,6 +177,10 @@ class SignalPacker:
 
     def set_nb(self, nb):
         self._check("rspt_hip_set_nb", self._L.rspt_hip_set_nb(self._h, nb))
+
+    def set_byte_order(self, big_endian=True):
+        """samples arrive (compress) and leave (decompress) with their bytes reversed (utils.cpp reverse_byte_order branches)"""
+        self._check("rspt_hip_set_byte_order", self._L.rspt_hip_set_byte_order(self._h, int(bool(big_endian))))
 
     def set_verify(self, on=True):
         """check every block's CRC-32C on decompress (hzr_verify's job in the reference); off by default"""
@@ -237,6 +259,21 @@ class SignalPacker:
         self._check("rspt_hip_pack_batch_dev", rc)
         return d_packed, d_total
 
+    def iir_prefilter_batch(self, d_buf, n, d, init_nr_samples=2000, per_channel=False, stream=None):
+        """The reference's pre-filter step (rspt_test.cpp:116-136) on device-resident blocks, in place; asynchronous."""
+        import torch
+
+        assert d_buf.is_cuda and d_buf.dtype == torch.uint8 and d_buf.is_contiguous()
+        nblocks = d_buf.numel() // self.block_bytes
+        assert nblocks * self.block_bytes == d_buf.numel()
+        nn, dd = np.ascontiguousarray(n, dtype=np.float64), np.ascontiguousarray(d, dtype=np.float64)
+        assert nn.size == dd.size
+        st = stream if stream is not None else torch.cuda.current_stream(d_buf.device).cuda_stream
+        rc = self._L.rspt_hip_iir_prefilter_batch_dev(self._h, d_buf.data_ptr(), nblocks, nn.ctypes.data_as(C.POINTER(C.c_double)),
+                                                      dd.ctypes.data_as(C.POINTER(C.c_double)), nn.size, init_nr_samples, int(bool(per_channel)), st)
+        self._check("rspt_hip_iir_prefilter_batch_dev", rc)
+        return d_buf
+
     def synchronize(self):
         self._check("rspt_hip_synchronize", self._L.rspt_hip_synchronize(self._h))
 
@@ -257,6 +294,29 @@ class SignalPacker:
         ms = (C.c_float * n)()
         self._check("rspt_hip_stage_times", self._L.rspt_hip_stage_times(self._h, ms, n))
         return {self._L.rspt_hip_stage_name(self._h, i).decode(): float(ms[i]) for i in range(n)}
+
+
+class HostBuffer:
+    """page-locked host memory (rspt_hip_host_alloc) as a numpy uint8 array: `.a`"""
+
+    def __init__(self, nbytes):
+        self._L = lib()
+        self._p = self._L.rspt_hip_host_alloc(nbytes)
+        if not self._p:
+            raise MemoryError("rspt_hip_host_alloc(%d)" % nbytes)
+        self.a = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self._p))
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.a = None
+            self._L.rspt_hip_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # factory names of lib_rspt/signal_packer.h:59-69

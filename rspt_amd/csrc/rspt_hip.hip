@@ -24,6 +24,7 @@
 #include "hzr_rows.hip"
 #include "transforms.hip"
 #include "decode.hip"
+#include "filter.hip"
 
 using namespace rspt;
 
@@ -178,6 +179,9 @@ struct rspt_hip_packer {
     uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
     uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
+    int big_endian = 0;   // samples arrive / leave with their bytes reversed (rspt_hip_set_byte_order)
+    uint8_t* swapbuf = nullptr;  // [cap * block_bytes] byte-swapped copy of the input
+    size_t swapbuf_bytes = 0;
 
     // the small-block encoder runs beside the big one (it fills the CUs the persistent grid frees in its tail)
     hipStream_t side = nullptr;
@@ -320,6 +324,37 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
 template <int BPS>
 static void launch_fixup(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, uint32_t np, hipStream_t st) {
     launch_planes<BPS, true>(p, d_src, nblocks, np, 4 - np, p->nbuse, st);
+}
+
+static void launch_byteswap(rspt_hip_packer* p, const uint8_t* src, uint8_t* dst, size_t nblocks, hipStream_t st) {
+    const uint64_t ns = (uint64_t)nblocks * p->g.nch * p->g.ns;
+    const unsigned grid = (unsigned)std::min<uint64_t>((ns + 255) / 256, 16384);
+    switch (p->g.bps) {
+        case 2: hipLaunchKernelGGL((k_byteswap<2>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
+        case 3: hipLaunchKernelGGL((k_byteswap<3>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
+        case 4: hipLaunchKernelGGL((k_byteswap<4>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
+        default: break;  // one byte per sample: nothing to reverse
+    }
+}
+
+template <int BPS, int NC>
+static void launch_iir(rspt_hip_packer* p, uint8_t* buf, uint32_t B, const IirCoef& c, int per_channel, hipStream_t st) {
+    const Geom& g = p->g;
+    if (per_channel) {
+        const uint32_t threads = B * g.nch;
+        hipLaunchKernelGGL((k_iir<BPS, NC, false>), dim3((threads + 63) / 64), dim3(64), 0, st, buf, g.nch, g.ns, (uint64_t)g.block_bytes, c, B);
+    } else {
+        hipLaunchKernelGGL((k_iir<BPS, NC, true>), dim3((B + 63) / 64), dim3(64), 0, st, buf, g.nch, g.ns, (uint64_t)g.block_bytes, c, B);
+    }
+}
+template <int BPS>
+static void launch_iir_nc(rspt_hip_packer* p, uint8_t* buf, uint32_t B, const IirCoef& c, int per_channel, hipStream_t st) {
+    switch (c.nc) {
+        case 2: launch_iir<BPS, 2>(p, buf, B, c, per_channel, st); break;
+        case 3: launch_iir<BPS, 3>(p, buf, B, c, per_channel, st); break;
+        case 4: launch_iir<BPS, 4>(p, buf, B, c, per_channel, st); break;
+        default: launch_iir<BPS, 5>(p, buf, B, c, per_channel, st); break;
+    }
 }
 
 extern "C" {
@@ -603,6 +638,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
+    hipFree(p->swapbuf);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
     if (p->side) {
@@ -693,6 +729,19 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const uint32_t B = (uint32_t)nblocks;
 
     stamp(p, ST_PRE, st);
+    if (p->big_endian && g.bps > 1) {  // big-endian feed: a byte-reversed copy is what the front end reads
+        const size_t need = nblocks * (size_t)g.block_bytes + 64;
+        if (p->swapbuf_bytes < need) {
+            HIPCHK(p, hipStreamSynchronize(st));
+            hipFree(p->swapbuf);
+            p->swapbuf = nullptr;
+            p->swapbuf_bytes = 0;
+            if (hipMalloc(&p->swapbuf, need) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+            p->swapbuf_bytes = need;
+        }
+        launch_byteswap(p, src, p->swapbuf, nblocks, st);
+        src = p->swapbuf;
+    }
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     {
         const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
@@ -844,6 +893,22 @@ int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb) {
     return RSPT_HIP_OK;
 }
 
+int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian) {
+    if (!p) return RSPT_HIP_ERR_ARG;
+    p->big_endian = big_endian ? 1 : 0;
+    return RSPT_HIP_OK;
+}
+
+void* rspt_hip_host_alloc(size_t bytes) {
+    void* q = nullptr;
+    if (bytes == 0 || hipHostMalloc(&q, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return q;
+}
+
+void rspt_hip_host_free(void* q) {
+    if (q) hipHostFree(q);
+}
+
 int rspt_hip_set_verify(rspt_hip_packer* p, int on) {
     if (!p) return RSPT_HIP_ERR_ARG;
     p->verify = on ? 1 : 0;
@@ -886,7 +951,8 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
         *dst_len = (size_t)sz;
         return RSPT_HIP_ERR_DST_TOO_SMALL;
     }
-    HIPCHK(p, hipMemcpy(dst_host, p->h_dst, (size_t)sz, hipMemcpyDeviceToHost));
+    HIPCHK(p, hipMemcpyAsync(dst_host, p->h_dst, (size_t)sz, hipMemcpyDeviceToHost, p->stream));  // (a DMA at link rate into pinned memory)
+    HIPCHK(p, hipStreamSynchronize(p->stream));
     *dst_len = (size_t)sz;
     return RSPT_HIP_OK;
 }
@@ -979,6 +1045,7 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
             case 3: hipLaunchKernelGGL((k_planar_native<3>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
             default: hipLaunchKernelGGL((k_planar_native<4>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
         }
+        if (p->big_endian && g.bps > 1) launch_byteswap(p, (const uint8_t*)d_dst, (uint8_t*)d_dst, nblocks, st);
     }
     HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
@@ -1007,8 +1074,32 @@ int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_le
     HIPCHK(p, hipMemcpyAsync(&used, p->h_size, sizeof(used), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(p, hipStreamSynchronize(p->stream));
     if (used >> 63) return RSPT_HIP_ERR_CORRUPT;
-    HIPCHK(p, hipMemcpy(dst_host, p->h_src, p->g.block_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(p, hipMemcpyAsync(dst_host, p->h_src, p->g.block_bytes, hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(p, hipStreamSynchronize(p->stream));
     *src_len = (size_t)used;
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_iir_prefilter_batch_dev(rspt_hip_packer* p, void* d_buf, size_t nblocks, const double* n, const double* d, size_t nr_coefficients,
+                                     int init_nr_samples, int per_channel, void* stream) {
+    if (!p || !d_buf || !n || !d || nblocks == 0 || nblocks > 0x7FFFFFFFu / (p->g.nch ? p->g.nch : 1)) return RSPT_HIP_ERR_ARG;
+    if (nr_coefficients < 2 || nr_coefficients > 5 || init_nr_samples < 0 || init_nr_samples > (1 << 28)) return RSPT_HIP_ERR_ARG;  // filter_opt covers 2..5 (iir_filter.cpp:87-103)
+    HIPCHK(p, hipSetDevice(p->device));
+    IirCoef c{};
+    for (size_t i = 0; i < nr_coefficients; ++i) {
+        c.n[i] = n[i];
+        c.d[i] = d[i];
+    }
+    c.nc = (uint32_t)nr_coefficients;
+    c.init_steps = 4 * init_nr_samples;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p->g.bps) {
+        case 1: launch_iir_nc<1>(p, (uint8_t*)d_buf, (uint32_t)nblocks, c, per_channel, st); break;
+        case 2: launch_iir_nc<2>(p, (uint8_t*)d_buf, (uint32_t)nblocks, c, per_channel, st); break;
+        case 3: launch_iir_nc<3>(p, (uint8_t*)d_buf, (uint32_t)nblocks, c, per_channel, st); break;
+        default: launch_iir_nc<4>(p, (uint8_t*)d_buf, (uint32_t)nblocks, c, per_channel, st); break;
+    }
+    HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
 }
 

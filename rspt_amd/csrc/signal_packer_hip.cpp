@@ -12,6 +12,7 @@
 // Difference: a failure of the GPU path is reported on std::cerr and leaves
 // dst_len = 0 -- there is no CPU fallback to hide it.
 #include <cstddef>
+#include <cstdlib>
 #include <iostream>
 
 #include "../../include/rspt_hip.h"
@@ -19,10 +20,20 @@
 
 namespace {
 
+// Which GPU the factories place a packer on (the reference's constructors have no such argument; SURVEY.md section 5:
+// "env var only for device selection"): the calling thread's rspt_cxx_set_device() value if it set one, else the
+// RSPT_HIP_DEVICE environment variable, else device 0.  One packer per host thread, one thread per GPU: a shard per device.
+thread_local int t_device = -1;
+int factory_device() {
+    if (t_device >= 0) return t_device;
+    if (const char* e = std::getenv("RSPT_HIP_DEVICE")) return std::atoi(e);
+    return 0;
+}
+
 class signal_packer_hip : public i_signal_packer {
 public:
     signal_packer_hip(int kind, size_t bps, size_t nch, size_t ns, size_t nb) {
-        int rc = rspt_hip_packer_create(&h_, kind, bps, nch, ns, nb, 0);
+        int rc = rspt_hip_packer_create(&h_, kind, bps, nch, ns, nb, factory_device());
         if (rc != RSPT_HIP_OK) {
             std::cerr << "ERROR: rspt_hip_packer_create: " << rspt_hip_status_string(rc) << std::endl;
             h_ = nullptr;
@@ -90,6 +101,12 @@ void i_signal_packer::delete_hadamard(i_signal_packer* instance) { delete static
 // C shim so that non-C++ hosts (the Python tests) can drive the C++ factories
 // themselves, not just the C ABI underneath them.
 extern "C" {
+// device for the packers this THREAD creates from now on (-1: back to RSPT_HIP_DEVICE / 0); returns the previous setting
+int rspt_cxx_set_device(int device) {
+    const int prev = t_device;
+    t_device = device;
+    return prev;
+}
 void* rspt_cxx_new(int kind, size_t bps, size_t nch, size_t ns, size_t nb) {
     switch (kind) {
         case RSPT_HIP_KIND_HZR: return i_signal_packer::new_hzr(bps, nch, ns);

@@ -201,3 +201,31 @@ def dct_big_cases():
     table: 1 GiB at 16384; ~20 s per case here).  The reference's full stream is the fixture: the FFT path is held to it."""
     return [dict(name="synth2x16384_dct", kind="dct", bps=4, nch=2, ns=16384, nb=2,
                  data=np.ascontiguousarray(synth.synth_native(2, 16384, block_index=11, ecg=True).numpy().reshape(-1)))]
+
+
+# the reference's band-pass (0.4-200 Hz Butterworth @ 2000 Sps, lib_rspt_test/rspt_test.cpp:123-125) and two shorter filters
+# of lib_rspt/filter.h:104-112, as (n = feedback, d = feed-forward)
+IIR_BANDPASS = ([1.00000000000, -3.14332095199, 3.70064088865, -1.97083923944, 0.41351972908],
+                [0.06722876941, 0.00000000000, -0.13445753881, 0.00000000000, 0.06722876941])
+IIR_LOWPASS = ([1.00000000000, -1.56101807580, 0.64135153806], [0.02008336556, 0.04016673113, 0.02008336556])
+IIR_HIGHPASS = ([1.00000000000, -1.99955571171, 0.99955581039], [0.99977788053, -1.99955576105, 0.99977788053])
+
+
+def iir_cases():
+    """name, bps, nch, ns, (n, d), init_nr_samples, data: the pre-filter step of rspt_test.cpp:116-136 on the repo's two
+    recordings (the harness's own use) and on synthetic blocks of every sample width / filter order."""
+    ecg = np.frombuffer(synth.ecg_12ch_i32(), dtype=np.uint8)
+    ds = np.frombuffer(synth.data_stream_3ch_i24(), dtype=np.uint8)
+    C = []
+
+    def add(name, bps, nch, ns, coef, init, data):
+        data = np.ascontiguousarray(data[: bps * nch * ns])
+        C.append(dict(name=name, bps=bps, nch=nch, ns=ns, n=coef[0], d=coef[1], init=init, data=data))
+
+    add("ecg12x34199_bandpass", 4, 12, 34199, IIR_BANDPASS, 2000, ecg)
+    add("ds3x20000_i24_bandpass", 3, 3, 20000, IIR_BANDPASS, 2000, ds)
+    add("synth5x3000_i16_lowpass", 2, 5, 3000, IIR_LOWPASS, 500, synth.synth_native(5, 3000, 3, bps=2, ecg=True).numpy())
+    add("synth4x2500_i32_highpass", 4, 4, 2500, IIR_HIGHPASS, 100, synth.synth_native(4, 2500, 4, ecg=True).numpy())
+    add("rand7x1001_i8_order1", 1, 7, 1001, ([1.0, -0.9], [0.05, 0.05]), 50, _rand_native(7, 1001, 1, 51, 100))
+    add("rand3x777_i24_order3", 3, 3, 777, ([1.0, -1.2, 0.5, -0.05], [0.1, 0.2, 0.2, 0.1]), 0, _rand_native(3, 777, 3, 52, 1 << 20))
+    return C

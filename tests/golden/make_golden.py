@@ -16,6 +16,8 @@ import struct
 import sys
 import zlib
 
+import numpy as np
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
@@ -86,6 +88,19 @@ def main():
         }
         print("%-28s %-10s size %8d prdn %s" % (c["name"], c["kind"], len(s), out["dct_big"][c["name"]]["prdn"]))
         pk.close()
+    out["iir"] = {}
+    for c in cases.iir_cases():
+        filt = ref.iir_prefilter(c["data"], c["bps"], c["nch"], c["ns"], c["n"], c["d"], c["init"])
+        # and what the harness does next (rspt_test.cpp:141-142): xdelta_hzr on the filtered block
+        pk = ref.packer("xdelta_hzr", c["bps"], c["nch"], c["ns"], 3)
+        s = pk.compress(np.frombuffer(filt, dtype=np.uint8))
+        pk.close()
+        out["iir"][c["name"]] = {
+            "bps": c["bps"], "nch": c["nch"], "ns": c["ns"], "n": c["n"], "d": c["d"], "init": c["init"],
+            "in_crc32": zlib.crc32(c["data"].tobytes()), "filtered_crc32": zlib.crc32(filt), "filtered_fnv1a": orc.fnv1a(filt),
+            "xdelta_size": len(s), "xdelta_fnv1a": orc.fnv1a(s),
+        }
+        print("%-28s filtered crc %08x xdelta %d" % (c["name"], zlib.crc32(filt), len(s)))
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "golden.json"))

@@ -1,0 +1,123 @@
+"""Host-side pieces around the path: big-endian ingest (lib_signalpacker/utils.cpp reverse_byte_order branches),
+page-locked staging buffers for the host-pointer API, and the C++ factories' device placement."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _reverse_samples(native, bps):
+    return np.ascontiguousarray(native.reshape(-1, bps)[:, ::-1]).reshape(-1)
+
+
+@pytest.mark.parametrize("bps", [1, 2, 3, 4])
+def test_reference_big_endian_ingest_is_a_byte_reversal(ref, bps):
+    """convert_native_to_i32(reverse_byte_order=true) of the byte-reversed block == the little-endian conversion
+    (utils.cpp:127-137,145-154,162-170,178-184): what the GPU's big-endian mode relies on -- pinned by the REAL reference"""
+    nch, ns = 3, 257
+    le = cases._rand_native(nch, ns, bps, 700 + bps, 1 << (8 * bps - 2))
+    be = _reverse_samples(le, bps)
+    a = ref.native_to_i32(le, ns, nch, bps, reverse_byte_order=False)
+    b = ref.native_to_i32(be, ns, nch, bps, reverse_byte_order=True)
+    assert (a == b).all()
+    if bps > 1:  # (the reference's 1-byte reverse branch of convert_i32_to_native writes at offset +1: utils.cpp:116-118)
+        assert ref.i32_to_native(a, bps, reverse_byte_order=True) == be.tobytes()
+
+
+def test_cxx_shard_example_compiles(tmp_path):
+    """tests/cxx/shard_devices.cpp: one packer per device on one thread each, through include/signal_packer.h alone"""
+    from rspt_amd import build
+
+    exe = tmp_path / "shard_devices"
+    lib_dir = os.path.dirname(build.LIB)
+    subprocess.check_call(["g++", "-std=c++11", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "shard_devices.cpp"),
+                           "-o", str(exe), "-L" + lib_dir, "-lrspt_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert exe.exists()
+
+
+@pytest.fixture(scope="module")
+def api():
+    from rspt_amd import api as a
+
+    assert a.lib().rspt_hip_device_count() > 0, "no gfx950 device visible"
+    return a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ds3x20000_i24_xdelta", "esc_i16_big", "ecg12x8192_xdelta", "sine16384_i8_xdelta", "ds3x16384_i24_hadamard"])
+def test_big_endian_feed(api, orc, golden, packer_cases, name):
+    """a big-endian feed compresses to the stream of the byte-reversed block, and decompress hands big-endian samples back"""
+    import torch
+
+    c, g = packer_cases[name], golden["packers"][name]
+    be = _reverse_samples(c["data"], c["bps"])
+    pk = api.SignalPacker(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    pk.set_byte_order(big_endian=True)
+    got = pk.compress(be)
+    assert len(got) == g["size"] and orc.fnv1a(got) == g["fnv1a"]
+    dec, used = pk.decompress(got)
+    assert used == len(got)
+    if g["lossless"]:
+        assert dec == be.tobytes()
+    # batched form, and back to little-endian on the same handle
+    d = torch.from_numpy(np.stack([be, be])).cuda()
+    d_dst, d_sizes = pk.compress_batch(d)
+    torch.cuda.synchronize()
+    assert d_dst[1, : int(d_sizes[1])].cpu().numpy().tobytes() == got or c["kind"] == "xdelta_hzr"  # (xdelta: nb may have escalated after call 1)
+    pk.set_byte_order(big_endian=False)
+    pk2 = api.SignalPacker(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    assert pk2.compress(c["data"]) == got
+    pk.close()
+    pk2.close()
+
+
+@pytest.mark.gpu
+def test_host_api_with_page_locked_buffers(api, orc):
+    """rspt_hip_host_alloc: the host-pointer entry points on page-locked buffers (DMA at link rate) give the same bytes"""
+    from rspt_amd import synth
+
+    nch, ns = 12, 8192
+    x = synth.synth_native(nch, ns, block_index=7).numpy().reshape(-1)
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    src, dst, back = api.HostBuffer(x.size), api.HostBuffer(2 * x.size), api.HostBuffer(x.size)
+    src.a[:] = x
+    n = pk.compress_into(src.a, dst.a)
+    want = orc.packer("xdelta_hzr", 4, nch, ns, 3).compress(x)
+    assert dst.a[:n].tobytes() == want
+    used = pk.decompress_into(dst.a, back.a)
+    assert used == n and back.a.tobytes() == x.tobytes()
+    for b in (src, dst, back):
+        b.close()
+    pk.close()
+
+
+@pytest.mark.gpu
+def test_cxx_factories_follow_the_device_setting(api, tmp_path):
+    """RSPT_HIP_DEVICE / rspt_cxx_set_device place the C++ factories' packers; the sharding example runs on every visible GPU"""
+    from rspt_amd import build
+
+    L = api.lib()
+    ndev = L.rspt_hip_device_count()
+    prev = L.rspt_cxx_set_device(ndev)  # one past the last device: no packer, an error on stderr -- never a fall-back to device 0
+    assert prev == -1
+    dead = api.CxxSignalPacker("xdelta_hzr", 4, 1, 64, 3)  # (like the reference, the factory itself does not throw)
+    assert dead.compress(np.arange(64, dtype=np.int32).view(np.uint8)) == b""
+    dead.close()
+    L.rspt_cxx_set_device(ndev - 1)
+    pk = api.CxxSignalPacker("xdelta_hzr", 4, 1, 64, 3)
+    assert len(pk.compress(np.arange(64, dtype=np.int32).view(np.uint8))) > 0
+    pk.close()
+    L.rspt_cxx_set_device(-1)
+    exe = tmp_path / "shard_devices"
+    lib_dir = os.path.dirname(build.LIB)
+    subprocess.check_call(["g++", "-std=c++11", "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "shard_devices.cpp"),
+                           "-o", str(exe), "-L" + lib_dir, "-lrspt_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout
+    assert "ok" in out.stdout

@@ -1,5 +1,6 @@
 """PCIe-inclusive rate of the host-pointer entry points (rspt_hip_compress / rspt_hip_decompress): one 64ch x 65536
-x int32 block per call, buffers in pageable host memory, as the i_signal_packer drop-in sees it."""
+x int32 block per call, as the i_signal_packer drop-in sees it -- with the buffers in pageable host memory (what a caller of
+the reference has today) and in page-locked memory from rspt_hip_host_alloc (DMA at link rate)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,16 +9,25 @@ from rspt_amd import api, synth
 nch, ns = 64, 65536
 x = synth.synth_native(nch, ns, block_index=1).numpy().reshape(-1)
 pk = api.new_xdelta_hzr(4, nch, ns, 3)
-out = pk.compress(x)
-t0 = time.perf_counter(); n = 0
-while time.perf_counter() - t0 < 3.0:
-    out = pk.compress(x); n += 1
-dt = time.perf_counter() - t0
-print("compress  : %.1f MSamples/s (%.2f ms per 16 MiB block, %d B out)" % (n * nch * ns / dt / 1e6, dt / n * 1e3, len(out)))
-dec, used = pk.decompress(out)
-assert dec == x.tobytes() and used == len(out)
-t0 = time.perf_counter(); n = 0
-while time.perf_counter() - t0 < 3.0:
-    pk.decompress(out); n += 1
-dt = time.perf_counter() - t0
-print("decompress: %.1f MSamples/s (%.2f ms per block)" % (n * nch * ns / dt / 1e6, dt / n * 1e3))
+
+
+def rate(label, src, dst, back):
+    n = pk.compress_into(src, dst)
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 3.0:
+        n = pk.compress_into(src, dst); k += 1
+    dt = time.perf_counter() - t0
+    print("%-12s compress  : %8.1f MSamples/s (%.3f ms per 16 MiB block, %d B out)" % (label, k * nch * ns / dt / 1e6, dt / k * 1e3, n))
+    used = pk.decompress_into(dst, back)
+    assert used == n and back.tobytes() == x.tobytes()
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 3.0:
+        pk.decompress_into(dst, back); k += 1
+    dt = time.perf_counter() - t0
+    print("%-12s decompress: %8.1f MSamples/s (%.3f ms per block)" % (label, k * nch * ns / dt / 1e6, dt / k * 1e3))
+
+
+rate("pageable", x.copy(), np.empty(2 * x.size, dtype=np.uint8), np.empty(x.size, dtype=np.uint8))
+hs, hd, hb = api.HostBuffer(x.size), api.HostBuffer(2 * x.size), api.HostBuffer(x.size)
+hs.a[:] = x
+rate("page-locked", hs.a, hd.a, hb.a)
