@@ -50,6 +50,8 @@ def parse_args(argv=None):
     ap.add_argument("--nb", type=int, default=3)
     ap.add_argument("--bps", type=int, default=4, choices=[1, 2, 3, 4], help="bytes per sample of the input (the metric is quoted on 4)")
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
+    ap.add_argument("--op", default="compress", choices=["compress", "decompress"],
+                    help="decompress: the timed step decodes the streams of one batch (secondary line, c3 workload, one GPU)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="c3, N>1: ship every step's streams to rank 0 (link-bound beyond 2-3 GPUs: see DESIGN.md)")
@@ -248,8 +250,20 @@ def main():
     slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
     sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if (do_gather and not c5) else None
 
+    decomp = args.op == "decompress"
+    if decomp:  # the streams to decode: both batches compressed once, outside the timed region
+        assert not c5 and dist is None, "--op decompress is a one-GPU c3 line"
+        for s_ in range(2):
+            pk.compress_batch(d_src[s_], d_dst[s_], d_sizes[s_], dst_stride)
+        torch.cuda.synchronize()
+        d_back = torch.empty((B, pk.block_bytes), dtype=torch.uint8, device=dev)
+        d_used = torch.empty(B, dtype=torch.int64, device=dev)
+
     def one_step(i):
         slot = i & 1
+        if decomp:
+            pk.decompress_batch(d_dst[slot], B, dst_stride, d_back, d_used)
+            return
         if c5:
             # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step
             pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
@@ -317,6 +331,10 @@ def main():
 
     # outside the timed region: both batches once more, their first and last streams against the oracle
     verified = None
+    if decomp:  # the last decoded batch is the input again (lossless packers), and the decoder consumed every stream in full
+        last = (args.steps - 1) & 1
+        ok_len = bool(torch.equal(d_used, d_sizes[last]))
+        decode_ok = ok_len and (bool(torch.equal(d_back, d_src[last])) if args.packer in ("xdelta_hzr", "hzr") else True)
     for s in range(2):
         pk.compress_batch(d_src[s], d_dst[s], d_sizes[s], dst_stride)
     torch.cuda.synchronize()
@@ -334,6 +352,8 @@ def main():
                     verified = verified and abs(len(got_b) / max(1, len(want)) - 1) <= 0.01  # FFT path: CR gate, not bytes
                 else:
                     verified = verified and got_b == want
+        if decomp:
+            verified = verified and decode_ok
         if not verified:
             sys.stderr.write("bench.py: a produced stream DIFFERS from the oracle\n")
 
@@ -370,8 +390,10 @@ def main():
         copy_gbs = None
 
     if rank == 0:
-        dominant = max(acc, key=acc.get)
         alg_bytes = in_bytes + out_bytes  # bytes = input_bytes + output_bytes per launch
+        if decomp:  # the decoder's kernels are not bracketed one by one: the whole step stands for "the kernel"
+            acc = {"decompress_all": dt / args.steps * 1e3}
+        dominant = max(acc, key=acc.get)
         plane_bytes = B * nb_now * nch * ns  # what the front end hands to the hzr stage
         # the dominant kernel's OWN algorithmic bytes (what it has to read and write once), over its own duration
         own = {"preprocess": in_bytes + plane_bytes, "hzr_encode": plane_bytes + out_bytes, "hzr_fused": plane_bytes + out_bytes,
@@ -397,7 +419,7 @@ def main():
         shape = "%dch x %d int%d" % (nch, ns, 8 * args.bps)
         samples_job = total_blocks * nch * ns
         res = {
-            "metric": "MSamples/s compress (%s, %s)" % (args.packer, shape),
+            "metric": "MSamples/s %s (%s, %s)" % (args.op, args.packer, shape),
             "value": round(samples_job * args.steps / dt / 1e6, 1),
             "unit": "MSamples/s",
             "n_gpus": world,

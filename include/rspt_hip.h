@@ -38,6 +38,10 @@ enum rspt_hip_kind {
     RSPT_HIP_KIND_HADAMARD = 3    /* lib_signalpacker/signal_packer_hadamard.cpp:35-107  */
 };
 
+/* Test hook, OR-ed into `kind` at create: a dct packer takes the fp64 FFT path also where the bit-exact dense-table path
+ * would run (ns = 2^k <= 8192), so that the two can be compared with each other (tests/test_gpu_dct_fft.py). */
+#define RSPT_HIP_DCT_FORCE_FFT 0x100
+
 enum rspt_hip_status {
     RSPT_HIP_OK = 0,
     RSPT_HIP_ERR_ARG = -1,         /* bad kind / sizes (bps not 1..4, nb not 1..4, ns not 2^k for hadamard ...) */

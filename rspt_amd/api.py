@@ -16,6 +16,7 @@ from . import build as _build
 
 KIND_HZR, KIND_XDELTA_HZR, KIND_DCT, KIND_HADAMARD = 0, 1, 2, 3
 KINDS = {"hzr": 0, "xdelta_hzr": 1, "dct": 2, "hadamard": 3}
+DCT_FORCE_FFT = 0x100  # RSPT_HIP_DCT_FORCE_FFT (test hook, include/rspt_hip.h)
 
 # every symbol include/rspt_hip.h declares (tests check the library exports them all)
 C_ABI_SYMBOLS = [
@@ -118,10 +119,11 @@ class SignalPacker:
 
     def __init__(self, kind, bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel, nr_bytes_to_encode=3, device=0):
         self._L = lib()
-        self.kind = KINDS[kind] if isinstance(kind, str) else int(kind)
+        kind_flags = KINDS[kind] if isinstance(kind, str) else int(kind)
+        self.kind = kind_flags & 0xFF
         self.bps, self.nch, self.ns = bytes_per_channel, nr_of_channels, nr_of_samples_in_each_channel
         h = C.c_void_p()
-        rc = self._L.rspt_hip_packer_create(C.byref(h), self.kind, self.bps, self.nch, self.ns, nr_bytes_to_encode, device)
+        rc = self._L.rspt_hip_packer_create(C.byref(h), kind_flags, self.bps, self.nch, self.ns, nr_bytes_to_encode, device)
         if rc != 0:
             raise RsptHipError("rspt_hip_packer_create", rc)
         self._h = h

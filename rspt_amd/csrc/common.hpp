@@ -12,6 +12,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostics (timing probes that skip work, tuning knobs read from the environment, in-kernel time stamps) exist only in
+// builds with -DRSPT_DIAG (tools/: "RSPT_EXTRA_FLAGS=-DRSPT_DIAG python -m rspt_amd.build" into a separate library).  In the
+// product library the probe word is the constant 0: every probe branch folds away and no environment variable changes a result.
+#ifdef RSPT_DIAG
+#define RSPT_DIAG_ONLY(x) (x)
+#else
+#define RSPT_DIAG_ONLY(x) 0u
+#endif
+
 namespace rspt {
 
 constexpr uint32_t kHzrBlock = 65536;  // hzr_internal.h:109

@@ -533,7 +533,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     if (mine) {
         d.cend[tid] = dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
     }
-#ifdef RSPT_DEC_ONEROUND
+#if defined(RSPT_DIAG) && defined(RSPT_DEC_ONEROUND)  // timing probe, diagnostic builds only
     for (uint32_t round = 0; round < 1; ++round) {
 #else
     for (uint32_t round = 0; round < nchunk; ++round) {  // (bounded: the first wrong chunk is right after every round)
@@ -565,7 +565,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     for (uint32_t i = 0; i < w; ++i) pre += d.wsum[i];
     const uint32_t o0 = pre + incl - mycount;  // exact for every chunk up to the one that holds the end
     uint32_t e2 = 0, p2 = 0;
-#ifdef RSPT_DEC_NOWRITE
+#if defined(RSPT_DIAG) && defined(RSPT_DEC_NOWRITE)  // timing probe, diagnostic builds only
     if (mine && start < limit && o0 < out_size) dec_chunk<false>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
 #else
     if (mine && start < limit && o0 < out_size) dec_chunk<true>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);

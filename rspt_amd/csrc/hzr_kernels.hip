@@ -631,7 +631,8 @@ __device__ __forceinline__ void encode_small_block(uint32_t* cwt, uint32_t* img,
                                                    const uint32_t* __restrict__ nzflag, const BlockMeta* __restrict__ meta,
                                                    const uint32_t* __restrict__ cw, const uint32_t* __restrict__ tdesc,
                                                    const uint64_t* __restrict__ out_off, const CrcConsts* __restrict__ cc,
-                                                   uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate) {
+                                                   uint8_t* __restrict__ dst, uint64_t dst_stride, uint32_t ablate_arg) {
+    const uint32_t ablate = RSPT_DIAG_ONLY(ablate_arg);  // timing probes: diagnostic builds only
     const uint32_t l = lane_id();
     if (ablate & 512u) return;
     const uint32_t j = hb % g.nblk, k = (hb / g.nblk) % kMaxPlanes, b = hb / (g.nblk * kMaxPlanes);

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     for (uint32_t i = tid; i < 8 * g.nch; i += nthr) s_nz[i] = 0;
     __syncthreads();
 
-    const TileCtx tc{g, m_nch, s0, Tn, b, kfirst, kcount, RS, ablate, fixup, out, s_nz, nzflag};
+    const TileCtx tc{g, m_nch, s0, Tn, b, kfirst, kcount, RS, RSPT_DIAG_ONLY(ablate), fixup, out, s_nz, nzflag};
     // ---- per (channel, 16-sample group): load, transform, plane split ---------
     const uint32_t ngrp = (Tn + 15) >> 4;
     const uint32_t nitems = g.nch * ngrp;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         // skip the same-address atomic when the block's mask already has it (750 tiles x waves per block)
         mag = wave_or_u32(mag);
         const uint32_t f = (mag >= 0x80u ? 0x80u : 0u) | (mag >= 0x8000u ? 0x8000u : 0u) | (mag >= 0x800000u ? 0x800000u : 0u);
-        if (lane_id() == 0 && f && !(ablate & 131072u) && (__builtin_nontemporal_load(&needmask[b]) & f) != f) atomicOr(&needmask[b], f);
+        if (lane_id() == 0 && f && !(RSPT_DIAG_ONLY(ablate) & 131072u) && (__builtin_nontemporal_load(&needmask[b]) & f) != f) atomicOr(&needmask[b], f);
     }
     __syncthreads();
 
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
         const uint32_t nbytes = min(16u, Tn - colu * 16);
         const uint8_t* sp = out + (size_t)row * RS + colu * 16;
         uint8_t* dp = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + colu * 16;
-        if (ablate & 16384u) continue;  // timing probe: no stores
+        if (RSPT_DIAG_ONLY(ablate) & 16384u) continue;  // timing probe: no stores (diagnostic builds only)
         if (fast && nbytes == 16) {
             *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
         } else if (nbytes == 16) {  // a row that starts at any byte alignment (ns not a multiple of 16): unaligned 16-byte store
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
     uint8_t* out = lds;
     uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)kcount * g.nch * RS);
-    TileCtx tc{g, m_nch, 0, 0, 0, kfirst, kcount, RS, ablate, fixup, out, s_nz, nzflag};
+    TileCtx tc{g, m_nch, 0, 0, 0, kfirst, kcount, RS, RSPT_DIAG_ONLY(ablate), fixup, out, s_nz, nzflag};
     auto t_open = [&]() {
         tc.b = tw / tiles_per_block;
         tc.s0 = tile_s0(tw);
@@ -577,12 +577,12 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         __syncthreads();
         if (XDELTA && !fixup && tid == 0) {
             const uint32_t f = s_nz[8 * g.nch];
-            if (f && !(ablate & 131072u)) atomicOr(&needmask[tc.b], f);
+            if (f && !(RSPT_DIAG_ONLY(ablate) & 131072u)) atomicOr(&needmask[tc.b], f);
         }
         // plane rows -> HBM: 16-byte units, T contiguous bytes per (plane, channel)
         const uint32_t upr = (tc.Tn + 15u) >> 4;
         const uint32_t nunits = kcount * g.nch * upr;
-        const bool whole_lines = (upr & 7u) == 0 && (tc.Tn & 15u) == 0 && !(ablate & (1u << 21));  // rows are whole 128-byte lines (else: store everything)
+        const bool whole_lines = (upr & 7u) == 0 && (tc.Tn & 15u) == 0 && !(RSPT_DIAG_ONLY(ablate) & (1u << 21));  // rows are whole 128-byte lines (else: store everything)
         const uint32_t m_upr = magic_of(upr);
         for (uint32_t u = tid; u < nunits; u += nthr) {
             const uint32_t row = fast_div(u, upr, m_upr);  // (k-kfirst)*nch + c
@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             const uint32_t c = row - kr * g.nch;
             const uint8_t* sp = out + (size_t)row * RS + colu * 16;
             uint8_t* dp = planes + ((size_t)tc.b * kMaxPlanes + kfirst + kr) * g.plane_stride + (size_t)c * g.ns + tc.s0 + colu * 16;
-            if (ablate & 16384u) continue;  // timing probe: no stores
+            if (RSPT_DIAG_ONLY(ablate) & 16384u) continue;  // timing probe: no stores (diagnostic builds only)
             const uint4 v = *reinterpret_cast<const uint4*>(sp);
             // a clean hzr block (zeros everywhere, see rspt_hip_packer::plane_dirty) only takes the 128-byte lines that hold
             // a non-zero byte: a line is eight consecutive units = eight aligned lanes (T is a multiple of 128)

@@ -177,7 +177,7 @@ struct rspt_hip_packer {
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
-    uint32_t ablate = 0;  // RSPT_ABLATE: timing-only diagnostic, see k_encode
+    uint32_t ablate = 0;  // RSPT_ABLATE (diagnostic builds only; the product kernels ignore it): timing probes
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
     int big_endian = 0;   // samples arrive / leave with their bytes reversed (rspt_hip_set_byte_order)
     uint8_t* swapbuf = nullptr;  // [cap * block_bytes] byte-swapped copy of the input
@@ -425,9 +425,11 @@ static void free_workspace(rspt_hip_packer* p) {
     p->cap_blocks = 0;
 }
 
-int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t nch, size_t ns, size_t nb, int device) {
+int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps, size_t nch, size_t ns, size_t nb, int device) {
     if (!out) return RSPT_HIP_ERR_ARG;
     *out = nullptr;
+    const bool force_fft = (kind_and_flags & RSPT_HIP_DCT_FORCE_FFT) != 0;  // (test hook, see rspt_hip.h)
+    const int kind = kind_and_flags & ~RSPT_HIP_DCT_FORCE_FFT;
     if (kind < 0 || kind > 3 || bps < 1 || bps > 4 || nch == 0 || ns == 0) return RSPT_HIP_ERR_ARG;
     if ((unsigned long long)nch * ns >= (1ull << 31)) return RSPT_HIP_ERR_ARG;  // the reference indexes with int
     if (kind == RSPT_HIP_KIND_XDELTA_HZR && (nb < 1 || nb > 4)) return RSPT_HIP_ERR_ARG;
@@ -483,7 +485,9 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
             };
             uint32_t Tp = fit(79 * 1024);
             if (Tp < 16) Tp = fit(150 * 1024);
-            if (const char* e = getenv("RSPT_TILE")) Tp = (uint32_t)atoi(e) & ~15u;  // tuning knob
+#ifdef RSPT_DIAG
+            if (const char* e = getenv("RSPT_TILE")) Tp = (uint32_t)atoi(e) & ~15u;  // tuning knob (diagnostic builds only)
+#endif
             if (Tp < 16) {
                 delete p;
                 return RSPT_HIP_ERR_UNSUPPORTED;
@@ -492,9 +496,11 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
             p->Tp[kc] = Tp;
         }
     }
+#ifdef RSPT_DIAG  // timing probes and tuning knobs: never in the product library
     if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
     if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
     if (const char* e = getenv("RSPT_K1_GRID")) p->k1_grid = (uint32_t)atoi(e);
+#endif
     if (p->k1_threads < 64 || p->k1_threads > 256) p->k1_threads = 256;  // (k_tile_planes is compiled for <= 256)
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
     {
@@ -515,9 +521,8 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
     if (kind == RSPT_HIP_KIND_DCT) {
         // n <= 8192: the reference's dense n x n table (bit-exact).  Larger n (where the reference cannot run):
         // fp64 FFT path, n = 2^k only.  RSPT_DCT_FFT=1 forces the FFT path for small n (cross-check against the table path).
-        const char* force = getenv("RSPT_DCT_FFT");
         const bool pow2 = (ns & (ns - 1)) == 0;
-        p->dct_fft = ns > 8192 || (force && atoi(force) != 0 && pow2 && ns >= 16);
+        p->dct_fft = ns > 8192 || (force_fft && pow2 && ns >= 16);
         if (p->dct_fft && (!pow2 || ns > (1u << 22))) {
             delete p;
             return RSPT_HIP_ERR_UNSUPPORTED;
@@ -527,8 +532,11 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind, size_t bps, size_t n
             while ((1ull << k) < ns) ++k;
             p->fft_l1 = (k + 1) / 2;
             p->fft_l2 = k / 2;
-            const char* noreal = getenv("RSPT_DCT_REAL");
-            if (k >= 8 && !(noreal && atoi(noreal) == 0)) {  // n/2 = m1*m2 with m2 = 64 where it can be (whole-line output runs)
+            bool real_form = true;
+#ifdef RSPT_DIAG
+            if (const char* noreal = getenv("RSPT_DCT_REAL")) real_form = atoi(noreal) != 0;  // complex-input form, for comparison
+#endif
+            if (k >= 8 && real_form) {  // n/2 = m1*m2 with m2 = 64 where it can be (whole-line output runs)
                 const uint32_t lM = k - 1;
                 p->fftr_lb = lM > 18 ? lM - 12 : 6;
                 p->fftr_la = lM - p->fftr_lb;
@@ -813,14 +821,17 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     hipLaunchKernelGGL(k_histlist, dim3((nhb + 255) / 256), dim3(256), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, p->work_ctr + 2);
     hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->hist, p->seghist, p->work_ctr, p->big_list,
                        p->work_ctr + 2, p->lists, p->listinfo);
+    HIPCHK(p, hipGetLastError());  // (a failing launch is reported at its own stage)
 
     stamp(p, ST_TREE, st);
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
+    HIPCHK(p, hipGetLastError());
 
     stamp(p, ST_LAYOUT, st);
     WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
                        d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift);
+    HIPCHK(p, hipGetLastError());
 
     stamp(p, ST_ENCODE, st);
     {

@@ -3,7 +3,7 @@
 The reference cannot run there (n x n float table), so the checker is the fp64 restatement in
 oracle/oracle.py (dct_big_*), itself compared with the real reference at ns <= 8192 in
 tests/test_oracle_dct_big.py.  Gate: |PRDN_gpu - PRDN_oracle| <= 0.05 percentage points and
-|CR_gpu / CR_oracle - 1| <= 1 %.  With RSPT_DCT_FFT=1 the same FFT kernels run at small ns, where the stream
+|CR_gpu / CR_oracle - 1| <= 1 %.  With RSPT_HIP_DCT_FORCE_FFT the same FFT kernels run at small ns, where the stream
 of the bit-exact table path (== the reference's) is available for comparison."""
 import os
 
@@ -58,9 +58,7 @@ def _coeff_mismatch(orc, a, b, bps, nch, ns):
 def test_forced_fft_path_vs_reference_arithmetic(api, orc, nch, ns, monkeypatch):
     data = _block(nch, ns, 3)
     want = orc.packer("dct", 4, nch, ns).compress(data)  # the reference's arithmetic (pinned in test_oracle_vs_ref)
-    monkeypatch.setenv("RSPT_DCT_FFT", "1")
-    pk = api.new_dct(4, nch, ns)
-    monkeypatch.delenv("RSPT_DCT_FFT")
+    pk = api.SignalPacker(api.KIND_DCT | api.DCT_FORCE_FFT, 4, nch, ns, 2)  # the FFT kernels where the table path would run
     got = pk.compress(data)
     frac, dmax = _coeff_mismatch(orc, got, want, 4, nch, ns)
     assert dmax <= 1 and frac <= 2e-3, (frac, dmax)  # only truncation-boundary flips
