@@ -14,10 +14,10 @@ import collections, csv, glob, json, os, sys
 STAGES = {
     "preprocess": ["k_tile_stream", "k_tile_planes", "k_planar_planes", "k_tile_planar", "k_fwht", "k_dct"],
     "nb_scan": ["k_nb_scan"],
-    "hzr_hist": ["k_hist"],
+    "hzr_hist": ["k_hist"],  # (k_histlist and k_hist)
     "hzr_tree": ["k_tree"],
     "layout": ["k_layout"],
-    "hzr_encode": ["k_encode<"],
+    "hzr_encode": ["k_encode("],
     "hzr_encode_small": ["k_encode_small"],
 }
 
@@ -42,8 +42,8 @@ def main():
     out = sys.argv[3] if len(sys.argv) > 3 else None
     ft, fc = collect(fdir, "FETCH_SIZE")
     wt, wc = collect(wdir, "WRITE_SIZE")
-    ncall_f = fc["hzr_encode"] or 1   # one k_encode launch per compress_batch call
-    ncall_w = wc["hzr_encode"] or 1
+    ncall_f = fc["hzr_tree"] or 1   # one k_tree launch per compress_batch call
+    ncall_w = wc["hzr_tree"] or 1
     res = {}
     detail = {}
     for st in STAGES:
@@ -54,6 +54,10 @@ def main():
         res[st] = int(rd + wr)
         detail[st] = {"read_bytes": int(rd), "write_bytes": int(wr), "launches_per_call": fc[st] / ncall_f}
     res["_detail"] = detail
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+
+    res["_kernels_sha"] = bench.kernels_sha()  # bench.py reports these figures only for the sources they were measured on
     res["_note"] = ("HBM bytes per rspt_hip_compress_batch_dev call; FETCH_SIZE(KiB)*1024*2 (gfx950 correction) + "
                     "WRITE_SIZE(KiB)*1024; separate --pmc passes; calls counted = %d / %d" % (ncall_f, ncall_w))
     s = json.dumps(res, indent=1)
