@@ -130,6 +130,7 @@ constexpr uint32_t kLutBits = 10;
 constexpr uint32_t kLutSlow = 0xFFFFFFFFu;
 constexpr uint32_t kDecThreads = 1024;
 constexpr uint32_t kDecMinChunkBits = 256;
+constexpr uint32_t kSerialTreePayload = 4096;  // bytes: below it the tree is recovered by one wave (dec_block)
 
 constexpr uint32_t kNodeSlots = 528;
 struct DecLds {
@@ -359,6 +360,102 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(0, 0, 0, 0);  // zero runs = untouched bytes
     const uint32_t bit0 = skew * 8, bit_end = (skew + L) * 8;
     DEC_STAMP(1);
+    // Two recoveries of the same tree.  A light block (short payload: a handful of symbols) is parsed by ONE wave on the scalar
+    // unit in a few thousand cycles; the workgroup-wide version below it takes ~48 k cycles whatever the tree -- three quarters
+    // of a light block's decode time -- but wins on the 200-node trees of dense blocks, where the serial walk (~600 cycles
+    // per node: one wave issues an instruction every few cycles) would take 130 k.  The payload length decides; both are exact.
+    if (L < kSerialTreePayload) {
+    // RecoverTree (hzr_decode.c:263-333).  The description is pre-order: '1' + 9-bit symbol = leaf, '0' = branch followed by
+    // child_a then child_b; nodes are numbered in pre-order, so child_a = id + 1 and only child_b has to be stored.
+    //   parse   ONE wave walks the description on the scalar unit: its dwords sit in the lanes of two vector registers (fetched
+    //           with v_readlane into a 64-bit scalar window), the branches on the path from the root in the lanes of a third
+    //           (lane = depth), "already in child_b" as a bit per depth.  A leaf closes every branch whose child_b it ends;
+    //           the node behind it is the child_b of the deepest branch still in its child_a.  <= 521 short iterations, no
+    //           barrier -- the workgroup-wide pointer-doubling version this replaces took 28 barriers and 48 k cycles per
+    //           block, three quarters of a light block's decode time.
+    //   table   every thread walks its own 10-bit index down from the root (<= 10 dependent LDS reads, all threads at once):
+    //           a leaf on the way -> symbol | length, else the node where longer codes continue.
+    constexpr uint32_t kMaxDesc = 11u * kNumSym + 16u;  // description bits (11 S - 1) and a little slack
+    const uint32_t P = min(kMaxDesc, bit_end - bit0);
+    if (w == 0) {
+        const uint32_t w0 = bit0 >> 5;  // first dword of the description in the image
+        const uint32_t dv0 = d.stage[w0 + l], dv1 = d.stage[w0 + 64u + l];  // (the image is 64 KiB + slack: always in bounds)
+        unsigned long long win = (unsigned long long)read_lane(dv0, 0) >> (bit0 & 31u);
+        uint32_t navail = 32u - (bit0 & 31u), widx = 1;
+        uint32_t pp = 0, n = 0, depth = 0, inb = 0, nleaf = 0, bad = 0, done = 0;
+        uint32_t stk = 0;  // lane d: id of the branch at depth d on the current path
+        while (!done && !bad) {
+            if (navail < 10u) {
+                const uint32_t nw = widx < 64u ? read_lane(dv0, widx) : read_lane(dv1, min(widx - 64u, 63u));
+                win |= (unsigned long long)nw << navail;
+                navail += 32u;
+                ++widx;
+            }
+            const uint32_t bits = (uint32_t)win;
+            if (!(bits & 1u)) {  // branch
+                if (pp + 1u > P || n >= 2u * kNumSym - 1u || depth >= 31u) {  // (depth 32+: deeper than the reference's 32-bit codes)
+                    bad = 1;
+                    break;
+                }
+                if (l == 0) d.node[n] = 0u;  // child_b: filled in when its subtree starts
+                stk = l == depth ? n : stk;
+                inb &= ~(1u << depth);
+                ++depth;
+                ++n;
+                win >>= 1;
+                navail -= 1u;
+                pp += 1u;
+            } else {  // leaf
+                const uint32_t sym = (bits >> 1) & 511u;
+                if (pp + 10u > P || n >= 2u * kNumSym - 1u || sym > 260u) {
+                    bad = 1;
+                    break;
+                }
+                if (l == 0) d.node[n] = kNodeLeaf | sym;
+                ++n;
+                ++nleaf;
+                win >>= 10;
+                navail -= 10u;
+                pp += 10u;
+                // close the branches whose child_b this leaf ends: back to the deepest branch still in its child_a
+                const uint32_t open = ~inb & ((depth >= 32u ? 0u : (1u << depth)) - 1u);
+                if (!open) {
+                    done = 1;  // the root's subtree is complete (a single-leaf tree ends here at once)
+                } else {
+                    depth = 32u - (uint32_t)__clz((int)open);  // = index of that branch + 1
+                    const uint32_t x = read_lane(stk, depth - 1u);
+                    if (l == 0) d.node[x] = n;  // its child_b is the node that comes next
+                    inb |= 1u << (depth - 1u);
+                }
+            }
+        }
+        if (l == 0) {
+            d.err = (bad || !done || nleaf > (uint32_t)kNumSym || bit0 + pp > bit_end) ? 1u : 0u;
+            d.nnode = n;
+            d.nleaf = nleaf;
+            d.code0 = bit0 + pp;  // where the codes start
+        }
+    }
+    __syncthreads();
+    if (d.err) {  // (block-uniform) no complete tree inside the payload, too many nodes, a symbol out of range, too deep
+        if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+        return;
+    }
+    {
+        const uint32_t nn = d.nnode;
+        for (uint32_t e = tid; e < (1u << kLutBits); e += kDecThreads) {
+            uint32_t nd = 0, len = 0, wv = d.node[0];
+            while (!(wv & kNodeLeaf) && len < kLutBits) {
+                nd = min(((e >> len) & 1u) ? wv : nd + 1u, nn - 1u);
+                wv = d.node[nd];
+                ++len;
+            }
+            // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
+            d.lut[e] = (wv & kNodeLeaf) ? ((wv & 511u) | ((len ? len : 1u) << 9)) : (kLutLong | nd);  // longer codes continue from nd
+        }
+    }
+    __syncthreads();
+    } else {
     // RecoverTree (hzr_decode.c:263-333) in three steps.  The description is pre-order: '1' + 9-bit symbol = leaf, '0' = branch
     // followed by child_a then child_b.  Nodes are numbered in pre-order, so child_a = id + 1.
     //   A (one lane, scalar unit): cut the bit string into nodes; keep the count of subtrees still open after each
@@ -517,6 +614,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     if (__syncthreads_or((int)deep)) {  // deeper than the reference's decoder supports (hzr_decode.c: 32-bit codes)
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
+    }
     }
     const uint32_t code0 = d.code0;
     DEC_STAMP(2);
