@@ -856,6 +856,101 @@ __global__ __launch_bounds__(1024) void k_inv_scan_tiles(uint32_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------
+// The int32 fast path (ns % 256 == 0, nch % 4 == 0): the last pass writes the interleaved samples itself -- no planar
+// int32 round trip (1.07 GB written and read again per 64-block batch of the BASELINE shape).  The scan tile is a ROW of
+// sixteen lanes x 16 consecutive samples = 256 samples of one channel, scanned with row-local DPP steps; a workgroup takes
+// CG channels x (1024 / CG) * 16 samples, so that what it writes is whole sample rows of CG channels (256 bytes for 64).
+// ---------------------------------------------------------------------------
+constexpr uint32_t kRowTile = 256;
+
+// PASS 0: XOR total of every row tile.  PASS 1: its sum of o+128 (needs the XOR carries).  Flat array, N % 256 == 0.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_inv_rows(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ dec_nb, uint32_t nrow,
+                                                 uint32_t* __restrict__ txor, uint32_t* __restrict__ tsum) {
+    const uint32_t b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t i0 = (blockIdx.x * 256u + tid) * 16u;
+    if (i0 >= g.N) return;  // (whole rows leave together)
+    uint32_t v[16];
+    load_v16(planes, g, b, dec_nb[b], i0, 16u, v);
+    uint32_t x = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x ^= v[e];
+    const uint32_t xinc = row_scan_prefix(x, 0u, [](uint32_t a, uint32_t c) { return a ^ c; });
+    const size_t row = (size_t)b * nrow + (i0 >> 8);
+    if (PASS == 0) {
+        if ((tid & 15u) == 15u) txor[row] = xinc;
+        return;
+    }
+    uint32_t o = txor[row] ^ xinc ^ x, dsum = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        o ^= v[e];
+        dsum += o + 128u;
+    }
+    const uint32_t sinc = row_scan_prefix(dsum, 0u, [](uint32_t a, uint32_t c) { return a + c; });
+    if ((tid & 15u) == 15u) tsum[row] = sinc;
+}
+
+// element s of a channel's piece sits in column inv_col(s) of its LDS row: the sixteen words of a thread are rotated by
+// (thread / 4) so that the lanes of a wave, whose spans start 16 words apart, do not meet in four banks
+__device__ __forceinline__ uint32_t inv_col(uint32_t s) { return (s & ~15u) | ((s + (s >> 6)) & 15u); }
+
+template <bool XDELTA, int CG>
+__global__ __launch_bounds__(1024) void k_inv_native(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ dec_nb, uint32_t nrow,
+                                                    const uint32_t* __restrict__ txor, const uint32_t* __restrict__ tsum, uint8_t* __restrict__ dst) {
+    constexpr uint32_t TPC = 1024u / CG, S = TPC * 16u, ROW = S + 1u;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint32_t* tile = reinterpret_cast<uint32_t*>(lds);  // [CG][ROW]
+    const uint32_t tid = threadIdx.x, c = tid / TPC, q = tid % TPC;
+    const uint32_t b = blockIdx.z, cg0 = blockIdx.y * CG, s0 = blockIdx.x * S;
+    const uint32_t ncg = min((uint32_t)CG, g.nch - cg0);
+    const uint32_t Sn = min(S, g.ns - s0);  // a multiple of 256
+    if (c < ncg && q * 16u < Sn) {  // (row-uniform)
+        const uint32_t i0 = (cg0 + c) * g.ns + s0 + q * 16u;
+        uint32_t v[16], p[16];
+        load_v16(planes, g, b, dec_nb[b], i0, 16u, v);
+        if (XDELTA) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x ^= v[e];
+            const uint32_t xinc = row_scan_prefix(x, 0u, [](uint32_t a, uint32_t d) { return a ^ d; });
+            const size_t row = (size_t)b * nrow + (i0 >> 8);
+            uint32_t o = txor[row] ^ xinc ^ x, dsum = 0;  // xor_decode_32 (utils.cpp:232-236), offset_32(+128)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                o ^= v[e];
+                p[e] = o + 128u;
+                dsum += p[e];
+            }
+            const uint32_t sinc = row_scan_prefix(dsum, 0u, [](uint32_t a, uint32_t d) { return a + d; });
+            uint32_t acc = tsum[row] + sinc - dsum;  // delta_decode (utils.cpp:204-213)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                acc += p[e];
+                p[e] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) p[e] = v[e];
+        }
+        uint32_t* r = tile + c * ROW + q * 16u;
+        const uint32_t rot = q >> 2;
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) r[(e + rot) & 15u] = p[e];
+    }
+    __syncthreads();
+    // sample rows out: 16-byte pieces (sample t, channels 4 c4 .. 4 c4 + 3), channel fastest
+    const uint32_t cpr = ncg >> 2;
+    const uint32_t total = Sn * cpr;
+    uint8_t* o = dst + (size_t)b * g.block_bytes;
+    for (uint32_t u = tid; u < total; u += 1024u) {
+        const uint32_t t = u / cpr, c4 = u - t * cpr;
+        const uint32_t* r = tile + (4u * c4) * ROW + inv_col(t);
+        *reinterpret_cast<uint4*>(o + ((size_t)(s0 + t) * g.nch + cg0 + 4u * c4) * 4u) = make_uint4(r[0], r[ROW], r[2 * ROW], r[3 * ROW]);
+    }
+}
+
 // [nch][ns] int32 -> interleaved native bytes (convert_i32_to_native, utils.cpp:51-121, LE branches)
 template <int BPS>
 __global__ __launch_bounds__(256) void k_planar_native(const int32_t* __restrict__ planar, Geom g, uint32_t T, uint8_t* __restrict__ dst) {

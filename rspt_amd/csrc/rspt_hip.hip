@@ -357,6 +357,15 @@ static void launch_iir_nc(rspt_hip_packer* p, uint8_t* buf, uint32_t B, const Ii
     }
 }
 
+template <bool XDELTA, int CG>
+static void launch_inv_native(rspt_hip_packer* p, uint32_t B, uint32_t nrow, void* d_dst, hipStream_t st) {
+    const Geom& g = p->g;
+    constexpr uint32_t S = (1024u / CG) * 16u, lds = CG * (S + 1u) * 4u;  // > 64 KiB: the limit is raised per kernel
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_inv_native<XDELTA, CG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const dim3 ng((g.ns + S - 1) / S, (g.nch + CG - 1) / CG, B);
+    hipLaunchKernelGGL((k_inv_native<XDELTA, CG>), ng, dim3(1024), lds, st, p->planes, g, p->dec_nb, nrow, p->txor, p->tsum, (uint8_t*)d_dst);
+}
+
 extern "C" {
 
 const char* rspt_hip_status_string(int s) {
@@ -699,8 +708,9 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->means, max_blocks * (size_t)(g.hdr_len ? g.hdr_len : 4)) == hipSuccess;
     // planar int32 scratch: transform packers on compress, every packer on decompress
     ok &= hipMalloc(&p->planar, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
-    ok &= hipMalloc(&p->txor, max_blocks * (size_t)p->ntile * sizeof(uint32_t)) == hipSuccess;
-    ok &= hipMalloc(&p->tsum, max_blocks * (size_t)p->ntile * sizeof(uint32_t)) == hipSuccess;
+    const size_t nscan = std::max<size_t>(p->ntile, g.N / kRowTile + 1);  // tiles of 4096, or row tiles of 256 (k_inv_native)
+    ok &= hipMalloc(&p->txor, max_blocks * nscan * sizeof(uint32_t)) == hipSuccess;
+    ok &= hipMalloc(&p->tsum, max_blocks * nscan * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->blk_off, nhb * sizeof(uint64_t)) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->planar2, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {
@@ -1011,6 +1021,33 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         }
         const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_DCT;
         const dim3 tg(p->ntile, B);
+        // int32 samples of the two hzr packers: the last inverse pass writes the interleaved block itself (k_inv_native)
+        const bool direct = (g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_HZR) && g.bps == 4 && (g.nch & 3) == 0 &&
+                            g.ns % kRowTile == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0;
+        if (direct) {
+            const uint32_t nrow = g.N / kRowTile;
+            const dim3 rg((g.N / 16 + 255) / 256, B);
+            if (xd) {
+                hipLaunchKernelGGL((k_inv_rows<0>), rg, dim3(256), 0, st, p->planes, g, p->dec_nb, nrow, p->txor, p->tsum);
+                hipLaunchKernelGGL((k_inv_scan_tiles<true>), dim3(B), dim3(1024), 0, st, p->txor, nrow);
+                hipLaunchKernelGGL((k_inv_rows<1>), rg, dim3(256), 0, st, p->planes, g, p->dec_nb, nrow, p->txor, p->tsum);
+                hipLaunchKernelGGL((k_inv_scan_tiles<false>), dim3(B), dim3(1024), 0, st, p->tsum, nrow);
+            }
+            if (g.nch <= 16) {
+                if (xd)
+                    launch_inv_native<true, 16>(p, B, nrow, d_dst, st);
+                else
+                    launch_inv_native<false, 16>(p, B, nrow, d_dst, st);
+            } else {
+                if (xd)
+                    launch_inv_native<true, 64>(p, B, nrow, d_dst, st);
+                else
+                    launch_inv_native<false, 64>(p, B, nrow, d_dst, st);
+            }
+            if (p->big_endian) launch_byteswap(p, (const uint8_t*)d_dst, (uint8_t*)d_dst, nblocks, st);
+            HIPCHK(p, hipGetLastError());
+            return RSPT_HIP_OK;
+        }
         if (xd) {
             hipLaunchKernelGGL((k_inv_tile<0, true>), tg, dim3(256), 0, st, p->planes, g, p->dec_nb, p->ntile, p->txor, p->tsum, p->planar);
             hipLaunchKernelGGL((k_inv_scan_tiles<true>), dim3(B), dim3(1024), 0, st, p->txor, p->ntile);

@@ -131,6 +131,38 @@ def test_batched_decompress(api, orc):
     pk.close()
 
 
+@pytest.mark.parametrize("kind", ["xdelta_hzr", "hzr"])
+@pytest.mark.parametrize("nch,ns", [(4, 256), (12, 8192), (16, 1280), (20, 512), (64, 768), (68, 256), (132, 1024)])
+def test_batched_decompress_int32_direct_path(api, orc, kind, nch, ns):
+    """int32 samples, ns % 256 == 0, nch % 4 == 0: the last inverse pass writes the interleaved block itself
+    (k_inv_native: <= 16 channels per workgroup, 64, 64 + a partial group, several groups)."""
+    import torch
+
+    bps, B = 4, 3
+    blocks = [cases._rand_native(nch, ns, bps, 900 + 7 * i + nch, 30000 if i else 3, walk=bool(i & 1)) for i in range(B)]
+    po = orc.packer(kind, bps, nch, ns, 3)
+    streams = [po.compress(b) for b in blocks]
+    stride = (max(len(s) for s in streams) + 255) // 256 * 256
+    buf = np.zeros((B, stride), dtype=np.uint8)
+    for i, s in enumerate(streams):
+        buf[i, : len(s)] = np.frombuffer(s, dtype=np.uint8)
+    pk = api.SignalPacker(kind, bps, nch, ns, 3)
+    if kind == "xdelta_hzr":
+        pk.set_nb(orc.packer_nb(po))
+    d_out, d_used = pk.decompress_batch(torch.from_numpy(buf).cuda(), B, stride)
+    torch.cuda.synchronize()
+    for i in range(B):
+        assert int(d_used[i]) == len(streams[i])
+        want = po.decompress(streams[i])[0]
+        assert d_out[i].cpu().numpy().tobytes() == bytes(want), (kind, nch, ns, i)
+    if kind == "xdelta_hzr":  # big-endian samples out of the same path (byte swap behind it)
+        pk.set_byte_order(True)
+        d_be, _ = pk.decompress_batch(torch.from_numpy(buf).cuda(), B, stride)
+        torch.cuda.synchronize()
+        assert d_be[B - 1].cpu().numpy().view(">i4").astype("<i4").tobytes() == d_out[B - 1].cpu().numpy().tobytes()
+    pk.close()
+
+
 def test_verify_checks_block_crcs(api, orc, packer_cases):
     """rspt_hip_set_verify: what hzr_verify does in the reference (hzr_decode.c:569-624)"""
     c = packer_cases["ecg12_i32"] if "ecg12_i32" in packer_cases else next(v for v in packer_cases.values() if v["kind"] == "xdelta_hzr" and v["nch"] * v["ns"] > 100000)

@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RSPT_ABLATE"] = str(1 << 20)
+os.environ["RSPT_ABLATE"] = "128"
 import numpy as np, torch
 from rspt_amd import api, synth
 B, nch, ns = 64, 64, 65536
