@@ -864,10 +864,24 @@ __global__ __launch_bounds__(1024) void k_inv_scan_tiles(uint32_t* __restrict__ 
 // ---------------------------------------------------------------------------
 constexpr uint32_t kRowTile = 256;
 
-// PASS 0: XOR total of every row tile.  PASS 1: its sum of o+128 (needs the XOR carries).  Flat array, N % 256 == 0.
-template <int PASS>
+// One pass over the planes gives both carries.  The XOR total of a row tile is plain.  Its SUM depends on the XOR carry c
+// that enters it -- sum_i ((c ^ y_i) + 128) with y_i the tile-local XOR prefixes -- but only through the number of y_i
+// that have each bit set: with cnt_b of the 256 values holding bit b,
+//     sum_i (c ^ y_i) = sum_b 2^b (c_b ? 256 - cnt_b : cnt_b)          (mod 2^32).
+// The counts are kept bit-sliced: plane k holds bit k of every cnt_b (nine planes for counts up to 256), so that
+//     sum_b 2^b cnt_b [over the bits b in a mask m] = sum_k 2^k (P_k & m)    -- an integer sum of masked plane words.
+// k_inv_rows leaves (XOR total, P_0..P_8) per row tile; k_inv_scan_rows turns them into the two exclusive carries.
+constexpr uint32_t kRowPlanes = 9;
+constexpr uint32_t kRowRec = 1 + kRowPlanes;  // words per row tile record
+
+__device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t& s, uint32_t& cy) {
+    const uint32_t x = a ^ b;
+    s = x ^ c;
+    cy = (x & c) | (~x & a);  // majority (one v_bfi)
+}
+
 __global__ __launch_bounds__(256) void k_inv_rows(const uint8_t* __restrict__ planes, Geom g, const uint32_t* __restrict__ dec_nb, uint32_t nrow,
-                                                 uint32_t* __restrict__ txor, uint32_t* __restrict__ tsum) {
+                                                 uint32_t* __restrict__ rec) {
     const uint32_t b = blockIdx.y, tid = threadIdx.x;
     const uint32_t i0 = (blockIdx.x * 256u + tid) * 16u;
     if (i0 >= g.N) return;  // (whole rows leave together)
@@ -877,19 +891,109 @@ __global__ __launch_bounds__(256) void k_inv_rows(const uint8_t* __restrict__ pl
 #pragma unroll
     for (int e = 0; e < 16; ++e) x ^= v[e];
     const uint32_t xinc = row_scan_prefix(x, 0u, [](uint32_t a, uint32_t c) { return a ^ c; });
-    const size_t row = (size_t)b * nrow + (i0 >> 8);
-    if (PASS == 0) {
-        if ((tid & 15u) == 15u) txor[row] = xinc;
-        return;
-    }
-    uint32_t o = txor[row] ^ xinc ^ x, dsum = 0;
+    uint32_t y[16], o = xinc ^ x;  // XOR of the lanes below in the row
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         o ^= v[e];
-        dsum += o + 128u;
+        y[e] = o;
     }
-    const uint32_t sinc = row_scan_prefix(dsum, 0u, [](uint32_t a, uint32_t c) { return a + c; });
-    if ((tid & 15u) == 15u) tsum[row] = sinc;
+    // sixteen one-bit columns -> a 5-bit count per bit position (carry-save adders)
+    uint32_t P[kRowPlanes];
+    {
+        uint32_t s0, c0, s1, c1, s2, c2, s3, c3, s4, c4, t0, d0, t1, d1, u0, f0, u1, f1, u2, f2, h0, i0_;
+        full_add(y[0], y[1], y[2], s0, c0);
+        full_add(y[3], y[4], y[5], s1, c1);
+        full_add(y[6], y[7], y[8], s2, c2);
+        full_add(y[9], y[10], y[11], s3, c3);
+        full_add(y[12], y[13], y[14], s4, c4);
+        full_add(s0, s1, s2, t0, d0);
+        full_add(s3, s4, y[15], t1, d1);
+        P[0] = t0 ^ t1;
+        const uint32_t e0 = t0 & t1;
+        full_add(c0, c1, c2, u0, f0);
+        full_add(c3, c4, d0, u1, f1);
+        full_add(d1, e0, u0, u2, f2);
+        P[1] = u1 ^ u2;
+        const uint32_t g0 = u1 & u2;
+        full_add(f0, f1, f2, h0, i0_);
+        P[2] = h0 ^ g0;
+        const uint32_t j0 = h0 & g0;
+        P[3] = i0_ ^ j0;
+        P[4] = i0_ & j0;
+    }
+    // ... summed over the sixteen lanes of the row (ripple adders on the planes; lane 15 ends with the total)
+#define RSPT_ROW_ADD(CTRL, NP)                                  \
+    {                                                           \
+        uint32_t cy = 0;                                        \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k) {        \
+            const uint32_t other = dpp<CTRL>(0u, P[k]);         \
+            uint32_t sum;                                       \
+            full_add(P[k], other, cy, sum, cy);                 \
+            P[k] = sum;                                         \
+        }                                                       \
+        P[NP] = cy;                                             \
+    }
+    RSPT_ROW_ADD(0x111, 5)
+    RSPT_ROW_ADD(0x112, 6)
+    RSPT_ROW_ADD(0x114, 7)
+    RSPT_ROW_ADD(0x118, 8)
+#undef RSPT_ROW_ADD
+    if ((tid & 15u) == 15u) {
+        uint32_t* r = rec + ((size_t)b * nrow + (i0 >> 8)) * kRowRec;
+        r[0] = xinc;
+#pragma unroll
+        for (uint32_t k = 0; k < kRowPlanes; ++k) r[1 + k] = P[k];
+    }
+}
+
+// workgroup-wide inclusive scan of one value per thread (1024 threads), on top of a running carry
+template <bool XOR>
+__device__ __forceinline__ uint32_t wg_scan_incl(uint32_t v, uint32_t* s_w, uint32_t& carry) {
+    const uint32_t l = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t inc = XOR ? wave_scan_incl(v, 0u, [](uint32_t a, uint32_t c) { return a ^ c; })
+                       : wave_scan_incl(v, 0u, [](uint32_t a, uint32_t c) { return a + c; });
+    __syncthreads();  // (s_w is reused)
+    if (l == 63u) s_w[w] = inc;
+    __syncthreads();
+    uint32_t pre = carry, tot = carry;
+    for (uint32_t q = 0; q < 16; ++q) {
+        if (q < w) pre = XOR ? (pre ^ s_w[q]) : (pre + s_w[q]);
+        tot = XOR ? (tot ^ s_w[q]) : (tot + s_w[q]);
+    }
+    carry = tot;
+    return XOR ? (pre ^ inc) : (pre + inc);
+}
+
+// row tile records of one block -> exclusive XOR carry and exclusive sum carry of every row tile (one workgroup per block)
+__global__ __launch_bounds__(1024) void k_inv_scan_rows(const uint32_t* __restrict__ rec, uint32_t nrow, uint32_t* __restrict__ txor,
+                                                       uint32_t* __restrict__ tsum) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* r0 = rec + (size_t)blockIdx.x * nrow * kRowRec;
+    uint32_t* ox = txor + (size_t)blockIdx.x * nrow;
+    uint32_t* os = tsum + (size_t)blockIdx.x * nrow;
+    uint32_t carry_x = 0, carry_s = 0;
+    for (uint32_t base = 0; base < nrow; base += 1024) {
+        const uint32_t i = base + tid;
+        const bool in = i < nrow;
+        const uint32_t* r = r0 + (size_t)i * kRowRec;
+        const uint32_t x = in ? r[0] : 0u;
+        const uint32_t c = wg_scan_incl<true>(x, s_w, carry_x) ^ x;  // the XOR carry that enters row tile i
+        uint32_t sum = 0;
+        if (in) {
+            sum = kRowTile * c + kRowTile * 128u;
+#pragma unroll
+            for (uint32_t k = 0; k < kRowPlanes; ++k) {
+                const uint32_t pk = r[1 + k];
+                sum += ((pk & ~c) - (pk & c)) << k;
+            }
+        }
+        const uint32_t sinc = wg_scan_incl<false>(sum, s_w, carry_s);
+        if (in) {
+            ox[i] = c;
+            os[i] = sinc - sum;
+        }
+    }
 }
 
 // element s of a channel's piece sits in column inv_col(s) of its LDS row: the sixteen words of a thread are rotated by

@@ -142,6 +142,7 @@ struct rspt_hip_packer {
     int32_t* planar2 = nullptr;    // [cap][N] second int32 buffer (dct output / idct output)
     uint32_t* txor = nullptr;      // [cap][ntile] decode scans
     uint32_t* tsum = nullptr;      // [cap][ntile]
+    uint32_t* rowrec = nullptr;    // [cap][N / 256][kRowRec] row tile records of the int32 decode path (k_inv_rows)
     uint64_t* blk_off = nullptr;   // [cap*4*nblk] decode: hzr block offsets inside each stream
     CrcConsts* crc = nullptr;
     // dct (signal_packer_dct.cpp:60-74): COS[x][i] and its transpose, built on the host like the reference ctor
@@ -417,13 +418,14 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->planar2);
     hipFree(p->txor);
     hipFree(p->tsum);
+    hipFree(p->rowrec);
     hipFree(p->blk_off);
     hipFree(p->fft_scratch);
     hipFree(p->mean_i32);
     p->fft_scratch = nullptr;
     p->mean_i32 = nullptr;
     p->planar2 = nullptr;
-    p->txor = p->tsum = nullptr;
+    p->txor = p->tsum = p->rowrec = nullptr;
     p->blk_off = nullptr;
     p->planes = nullptr;
     p->planar = nullptr;
@@ -711,6 +713,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     const size_t nscan = std::max<size_t>(p->ntile, g.N / kRowTile + 1);  // tiles of 4096, or row tiles of 256 (k_inv_native)
     ok &= hipMalloc(&p->txor, max_blocks * nscan * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->tsum, max_blocks * nscan * sizeof(uint32_t)) == hipSuccess;
+    if (g.ns % kRowTile == 0 && g.bps == 4) ok &= hipMalloc(&p->rowrec, max_blocks * (g.N / kRowTile) * (size_t)kRowRec * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->blk_off, nhb * sizeof(uint64_t)) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->planar2, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {
@@ -1028,10 +1031,8 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
             const uint32_t nrow = g.N / kRowTile;
             const dim3 rg((g.N / 16 + 255) / 256, B);
             if (xd) {
-                hipLaunchKernelGGL((k_inv_rows<0>), rg, dim3(256), 0, st, p->planes, g, p->dec_nb, nrow, p->txor, p->tsum);
-                hipLaunchKernelGGL((k_inv_scan_tiles<true>), dim3(B), dim3(1024), 0, st, p->txor, nrow);
-                hipLaunchKernelGGL((k_inv_rows<1>), rg, dim3(256), 0, st, p->planes, g, p->dec_nb, nrow, p->txor, p->tsum);
-                hipLaunchKernelGGL((k_inv_scan_tiles<false>), dim3(B), dim3(1024), 0, st, p->tsum, nrow);
+                hipLaunchKernelGGL(k_inv_rows, rg, dim3(256), 0, st, p->planes, g, p->dec_nb, nrow, p->rowrec);
+                hipLaunchKernelGGL(k_inv_scan_rows, dim3(B), dim3(1024), 0, st, p->rowrec, nrow, p->txor, p->tsum);
             }
             if (g.nch <= 16) {
                 if (xd)
