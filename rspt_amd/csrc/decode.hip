@@ -174,80 +174,73 @@ __device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t 
 // Decode from bit `bp` until a code boundary >= `limit` (or the end of the payload).  Returns that boundary; `produced`
 // = output bytes of the tokens decoded.  WRITE: literals go to out[o0...] (bounded by out_size).
 // max_out: stop as soon as that many output bytes are produced (the last chunk: the final byte's pad bits are not codes).
-// The stream bits travel in a 64-bit register window that is refilled from LDS when fewer than 48 remain (a token is at
-// most 31 + 14 bits): one LDS access per ~4 tokens instead of two per token.
+// The loop is written without per-lane branches: 64 chunks advance in step, the wave leaves when none is active, and a lane
+// that is done (or met a bad code) keeps its state through selects.  With exec-mask branches for the refill, the long
+// codes and the error exits the token loop was ~75 scalar next to ~50 vector instructions, and the scalar pipe -- one
+// instruction per cycle for the whole CU -- was what bound it.  The 64 stream bits in front of `bp` are re-read from LDS
+// for every token (three words, two v_alignbit): cheaper than keeping a window and testing it.
 template <bool WRITE>
 __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint32_t limit, uint32_t bit_end, uint32_t& produced, uint8_t* out,
                                               uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
     uint32_t o = o0;
-    unsigned long long win = 0;
-    uint32_t navail = 0;
     uint32_t cur_dw = 0xFFFFFFFFu, acc = 0;  // WRITE: aligned output dword being assembled
-    while (bp < limit && o - o0 < max_out) {
-        if (navail < 48) {
-            const uint32_t wi = bp >> 5, sh = bp & 31u;
-            win = ((unsigned long long)d.stage[wi] | ((unsigned long long)d.stage[wi + 1] << 32)) >> sh;
-            navail = 64 - sh;  // >= 33; the bits past navail are zero, a token that needs them is past bit_end anyway
-            if (navail < 48) {  // sh > 16: top up with the third word
-                win |= (unsigned long long)d.stage[wi + 2] << navail;
-                navail += 32;  // (only the low 64 bits are kept: navail is capped below)
-                navail = navail > 64 ? 64 : navail;
-            }
-        }
-        const uint32_t bits = (uint32_t)win;
-        const uint32_t e = d.lut[bits & ((1u << kLutBits) - 1u)];
-        uint32_t sym, len;
-        if (!(e & kLutLong)) {
-            sym = e & 511u;
-            len = e >> 9;
-        } else {
-            // a code longer than the table index: walk on from the node the first 10 bits lead to (one LDS read per level).
-            // With 64 lanes in step some lane is here at almost every token, so this path has to be short.
-            if (e == kLutSlow) {  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
-                err = 1;
-                break;
-            }
-            uint32_t nd = e & 1023u, wv = d.node[nd];
-            len = kLutBits;
-            while (!(wv & kNodeLeaf) && len < 32) {
-                nd = min(((bits >> len) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
+    bool live = true;
+    for (;;) {
+        const bool active = live && bp < limit && o - o0 < max_out;
+        if (!__ballot(active)) break;
+        const uint32_t wi = bp >> 5, sh = bp & 31u;
+        const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1], w2 = d.stage[wi + 2];  // (a done lane reads inside the slack words)
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const uint32_t e = d.lut[lo & ((1u << kLutBits) - 1u)];
+        const bool islong = (e & kLutLong) != 0u;
+        bool bad = e == kLutSlow;  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
+        uint32_t sym = e & 511u, len = (e >> 9) & 63u;
+        if (__ballot(active && islong && !bad)) {
+            // codes longer than the table index: walk on from the node the first 10 bits lead to (one LDS read per level),
+            // all lanes in step; the others re-read a clamped slot and keep what they have
+            uint32_t nd = min(e & 1023u, kNodeSlots - 1u);
+            uint32_t wv = d.node[nd], len2 = kLutBits;
+            for (;;) {
+                const bool step = islong && !bad && !(wv & kNodeLeaf) && len2 < 32u;
+                if (!__ballot(step)) break;
+                const uint32_t nn = min(((lo >> (len2 & 31u)) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
+                nd = step ? nn : nd;
                 wv = d.node[nd];
-                ++len;
+                len2 += step ? 1u : 0u;
             }
-            if (!(wv & kNodeLeaf)) {
-                err = 1;
-                break;
-            }
-            sym = wv & 511u;
+            bad = bad || (islong && !(wv & kNodeLeaf));
+            sym = islong ? (wv & 511u) : sym;
+            len = islong ? len2 : len;
         }
         // literal: one byte.  Run symbols 256..260 (hzr_internal.h:117-121): 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14
-        // extra bits -- looked up in two packed constants, not branched on: with 64 lanes in step some lane holds a run
-        // symbol in a fifth of the iterations even on the dense plane
-        const bool lit = sym < 256;
+        // extra bits -- looked up in two packed constants
+        const bool lit = sym < 256u;
         const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
         const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
         const uint32_t zbase = ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
+        const unsigned long long win = ((unsigned long long)hi << 32) | lo;
         const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
-        if (WRITE && lit && o < out_size) {
+        const bool go = active && !bad;
+        err |= (active && bad) ? 1u : 0u;
+        if (WRITE) {
             // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
             // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
+            const bool put = go && lit && o < out_size;
             const uint32_t dw = o >> 2;
-            if (dw != cur_dw) {
-                if (acc) flush_dword(out, cur_dw, acc);
-                cur_dw = dw;
-                acc = 0;
+            const bool newdw = put && dw != cur_dw;
+            const bool fl = newdw && acc != 0u;
+            if (__ballot(fl)) {
+                if (fl) flush_dword(out, cur_dw, acc);
             }
-            acc |= sym << ((o & 3u) * 8);
+            acc = newdw ? 0u : acc;
+            cur_dw = newdw ? dw : cur_dw;
+            acc |= put ? sym << ((o & 3u) * 8u) : 0u;
         }
-        o += lit ? 1u : zbase + extra;
-        const uint32_t used = len + eb;
-        win >>= used;
-        navail -= used;
-        bp += used;
-        if (bp > bit_end) {  // ran over the payload
-            err = 1;
-            break;
-        }
+        o += go ? (lit ? 1u : zbase + extra) : 0u;
+        bp += go ? len + eb : 0u;
+        const bool over = go && bp > bit_end;  // ran over the payload
+        err |= over ? 1u : 0u;
+        live = live && !bad && !over;
     }
     if (WRITE && acc) flush_dword(out, cur_dw, acc);
     produced = o - o0;
