@@ -135,7 +135,7 @@ constexpr uint32_t kSerialTreePayload = 4096;  // bytes: below it the tree is re
 constexpr uint32_t kNodeSlots = 528;
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
-    uint32_t lut[1u << kLutBits];        // code of <= 10 bits: sym | len<<9;  longer: kLutLong | node reached after 10 bits
+    uint32_t lut[1u << kLutBits];        // code of <= 10 bits: tok_meta(sym) | len<<9;  longer: kLutLong | node reached after 10 bits
     uint32_t cend[kDecThreads];          // first code boundary past a chunk's end  (lut + cend: 8 KiB of scratch for the tree parse)
     uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
     uint32_t leaf_code[kSymStride];
@@ -179,6 +179,18 @@ __device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t 
 // codes and the error exits the token loop was ~75 scalar next to ~50 vector instructions, and the scalar pipe -- one
 // instruction per cycle for the whole CU -- was what bound it.  The 64 stream bits in front of `bp` are re-read from LDS
 // for every token (three words, two v_alignbit): cheaper than keeping a window and testing it.
+// What the token loop needs to know about a symbol, packed beside it: sym | extra bits << 15 | output bytes before the
+// extra value << 19 (1 for a literal -- symbol 0 included: one zero byte --, else the run's base length: hzr_internal.h:117-121,
+// 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14 extra bits).  A table entry adds the code length << 9.
+__device__ __forceinline__ uint32_t tok_meta(uint32_t sym) {
+    const bool lit = sym < 256u;
+    const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
+    const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
+    const uint32_t zb = lit ? 1u : ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
+    return sym | (eb << 15) | (zb << 19);
+}
+__device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 template <bool WRITE>
 __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint32_t limit, uint32_t bit_end, uint32_t& produced, uint8_t* out,
                                               uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
@@ -186,38 +198,32 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
     uint32_t cur_dw = 0xFFFFFFFFu, acc = 0;  // WRITE: aligned output dword being assembled
     bool live = true;
     for (;;) {
-        const bool active = live && bp < limit && o - o0 < max_out;
-        if (!__ballot(active)) break;
+        // (limit <= bit_end: a lane that ran over the payload is past its limit too -- tested once, behind the loop)
+        const bool active = live && bp < limit && (!WRITE || o - o0 < max_out);
+        if (!any_lane(active)) break;
         const uint32_t wi = bp >> 5, sh = bp & 31u;
         const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1], w2 = d.stage[wi + 2];  // (a done lane reads inside the slack words)
         const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-        const uint32_t e = d.lut[lo & ((1u << kLutBits) - 1u)];
+        uint32_t e = d.lut[lo & ((1u << kLutBits) - 1u)];
         const bool islong = (e & kLutLong) != 0u;
         bool bad = e == kLutSlow;  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
-        uint32_t sym = e & 511u, len = (e >> 9) & 63u;
-        if (__ballot(active && islong && !bad)) {
+        if (any_lane(active && islong && !bad)) {
             // codes longer than the table index: walk on from the node the first 10 bits lead to (one LDS read per level),
             // all lanes in step; the others re-read a clamped slot and keep what they have
             uint32_t nd = min(e & 1023u, kNodeSlots - 1u);
             uint32_t wv = d.node[nd], len2 = kLutBits;
             for (;;) {
                 const bool step = islong && !bad && !(wv & kNodeLeaf) && len2 < 32u;
-                if (!__ballot(step)) break;
+                if (!any_lane(step)) break;
                 const uint32_t nn = min(((lo >> (len2 & 31u)) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
                 nd = step ? nn : nd;
                 wv = d.node[nd];
                 len2 += step ? 1u : 0u;
             }
             bad = bad || (islong && !(wv & kNodeLeaf));
-            sym = islong ? (wv & 511u) : sym;
-            len = islong ? len2 : len;
+            e = islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
         }
-        // literal: one byte.  Run symbols 256..260 (hzr_internal.h:117-121): 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14
-        // extra bits -- looked up in two packed constants
-        const bool lit = sym < 256u;
-        const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
-        const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
-        const uint32_t zbase = ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
+        const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u, zb = (e >> 19) & 511u;
         const unsigned long long win = ((unsigned long long)hi << 32) | lo;
         const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
         const bool go = active && !bad;
@@ -225,23 +231,23 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
         if (WRITE) {
             // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
             // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
-            const bool put = go && lit && o < out_size;
+            const uint32_t sym = e & 511u;
+            const bool put = go && sym < 256u && o < out_size;
             const uint32_t dw = o >> 2;
             const bool newdw = put && dw != cur_dw;
             const bool fl = newdw && acc != 0u;
-            if (__ballot(fl)) {
+            if (any_lane(fl)) {
                 if (fl) flush_dword(out, cur_dw, acc);
             }
             acc = newdw ? 0u : acc;
             cur_dw = newdw ? dw : cur_dw;
             acc |= put ? sym << ((o & 3u) * 8u) : 0u;
         }
-        o += go ? (lit ? 1u : zbase + extra) : 0u;
+        o += go ? zb + extra : 0u;
         bp += go ? len + eb : 0u;
-        const bool over = go && bp > bit_end;  // ran over the payload
-        err |= over ? 1u : 0u;
-        live = live && !bad && !over;
+        live = live && !bad;
     }
+    if (bp > bit_end) err = 1;  // ran over the payload
     if (WRITE && acc) flush_dword(out, cur_dw, acc);
     produced = o - o0;
     return bp;
@@ -444,7 +450,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
                 ++len;
             }
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
-            d.lut[e] = (wv & kNodeLeaf) ? ((wv & 511u) | ((len ? len : 1u) << 9)) : (kLutLong | nd);  // longer codes continue from nd
+            d.lut[e] = (wv & kNodeLeaf) ? (tok_meta(wv & 511u) | ((len ? len : 1u) << 9)) : (kLutLong | nd);  // longer codes continue from nd
         }
     }
     __syncthreads();
@@ -599,7 +605,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
             const uint32_t elen = depth ? depth : 1u;
             if (elen <= kLutBits)  // every leaf of <= 10 bits owns the entries code + m * 2^len
-                for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = (w_node & 511u) | (elen << 9);
+                for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = tok_meta(w_node & 511u) | (elen << 9);
         } else if (depth == kLutBits) {
             d.lut[code] = kLutLong | i;  // codes longer than the table index continue from here
         }
