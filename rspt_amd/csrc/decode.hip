@@ -196,20 +196,23 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
                                               uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
     uint32_t o = o0;
     uint32_t cur_dw = 0xFFFFFFFFu, acc = 0;  // WRITE: aligned output dword being assembled
-    bool live = true;
+    uint32_t lim = limit;                    // 0 once the lane is done for good (its byte budget is spent, or a bad code)
     for (;;) {
         // (limit <= bit_end: a lane that ran over the payload is past its limit too -- tested once, behind the loop)
-        const bool active = live && bp < limit && (!WRITE || o - o0 < max_out);
+        if (WRITE) lim = o - o0 < max_out ? lim : 0u;
+        const bool active = bp < lim;
         if (!any_lane(active)) break;
         const uint32_t wi = bp >> 5, sh = bp & 31u;
         const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1], w2 = d.stage[wi + 2];  // (a done lane reads inside the slack words)
         const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
         uint32_t e = d.lut[lo & ((1u << kLutBits) - 1u)];
-        const bool islong = (e & kLutLong) != 0u;
-        bool bad = e == kLutSlow;  // no such code (a speculative round in the middle of raw bits, or a corrupt stream)
-        if (any_lane(active && islong && !bad)) {
-            // codes longer than the table index: walk on from the node the first 10 bits lead to (one LDS read per level),
-            // all lanes in step; the others re-read a clamped slot and keep what they have
+        e = active ? e : 0u;  // an entry of zero moves nothing: the lanes that are done idle through the rest
+        if (any_lane((int32_t)e < 0)) {
+            // kLutSlow: no such code (a speculative round in the middle of raw bits, or a corrupt stream).  Else a code longer
+            // than the table index: walk on from the node the first 10 bits lead to (one LDS read per level), all lanes in
+            // step; the others re-read a clamped slot and keep what they have
+            const bool islong = (int32_t)e < 0;
+            bool bad = e == kLutSlow;
             uint32_t nd = min(e & 1023u, kNodeSlots - 1u);
             uint32_t wv = d.node[nd], len2 = kLutBits;
             for (;;) {
@@ -221,18 +224,18 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
                 len2 += step ? 1u : 0u;
             }
             bad = bad || (islong && !(wv & kNodeLeaf));
-            e = islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
+            e = bad ? 0u : islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
+            lim = bad ? 0u : lim;
+            err |= bad ? 1u : 0u;
         }
         const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u, zb = (e >> 19) & 511u;
         const unsigned long long win = ((unsigned long long)hi << 32) | lo;
         const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
-        const bool go = active && !bad;
-        err |= (active && bad) ? 1u : 0u;
         if (WRITE) {
             // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
             // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
             const uint32_t sym = e & 511u;
-            const bool put = go && sym < 256u && o < out_size;
+            const bool put = active && sym < 256u && o < out_size;  // (an idle or stopped lane "puts" symbol 0: nothing)
             const uint32_t dw = o >> 2;
             const bool newdw = put && dw != cur_dw;
             const bool fl = newdw && acc != 0u;
@@ -243,9 +246,8 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
             cur_dw = newdw ? dw : cur_dw;
             acc |= put ? sym << ((o & 3u) * 8u) : 0u;
         }
-        o += go ? zb + extra : 0u;
-        bp += go ? len + eb : 0u;
-        live = live && !bad;
+        o += zb + extra;
+        bp += len + eb;
     }
     if (bp > bit_end) err = 1;  // ran over the payload
     if (WRITE && acc) flush_dword(out, cur_dw, acc);
