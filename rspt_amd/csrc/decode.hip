@@ -158,9 +158,10 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
 
 // One assembled output dword to memory.  A byte that is zero in `acc` is a zero-run byte (already zero in the output) or
 // belongs to a neighbour chunk (which may be writing it right now): only the non-zero bytes are stored, as one dword when
-// all four are there (the common case in a dense plane), else one by one.
+// all four are there (the common case in a dense plane), else one by one (an atomic OR of the dword instead was much slower).
 __device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t acc) {
-    if ((acc & 0x000000FFu) && (acc & 0x0000FF00u) && (acc & 0x00FF0000u) && (acc & 0xFF000000u)) {
+    const bool has_zero_byte = ((acc - 0x01010101u) & ~acc & 0x80808080u) != 0u;
+    if (!has_zero_byte) {
         reinterpret_cast<uint32_t*>(out)[dw] = acc;
     } else {
 #pragma unroll
@@ -171,23 +172,15 @@ __device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t 
     }
 }
 
-// Decode from bit `bp` until a code boundary >= `limit` (or the end of the payload).  Returns that boundary; `produced`
-// = output bytes of the tokens decoded.  WRITE: literals go to out[o0...] (bounded by out_size).
-// max_out: stop as soon as that many output bytes are produced (the last chunk: the final byte's pad bits are not codes).
-// The loop is written without per-lane branches: 64 chunks advance in step, the wave leaves when none is active, and a lane
-// that is done (or met a bad code) keeps its state through selects.  With exec-mask branches for the refill, the long
-// codes and the error exits the token loop was ~75 scalar next to ~50 vector instructions, and the scalar pipe -- one
-// instruction per cycle for the whole CU -- was what bound it.  The 64 stream bits in front of `bp` are re-read from LDS
-// for every token (three words, two v_alignbit): cheaper than keeping a window and testing it.
-// What the token loop needs to know about a symbol, packed beside it: sym | extra bits << 15 | output bytes before the
-// extra value << 19 (1 for a literal -- symbol 0 included: one zero byte --, else the run's base length: hzr_internal.h:117-121,
+// What the token loop needs to know about a symbol: literal byte (or 256 for any run) | extra bits << 15 | output bytes
+// before the extra value << 19 (1 for a literal -- symbol 0 included: one zero byte --, else the run's base length: hzr_internal.h:117-121,
 // 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14 extra bits).  A table entry adds the code length << 9.
 __device__ __forceinline__ uint32_t tok_meta(uint32_t sym) {
     const bool lit = sym < 256u;
     const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
     const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
     const uint32_t zb = lit ? 1u : ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
-    return sym | (eb << 15) | (zb << 19);
+    return (lit ? sym : 256u) | (eb << 15) | (zb << 19);
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
@@ -232,19 +225,18 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
         const unsigned long long win = ((unsigned long long)hi << 32) | lo;
         const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
         if (WRITE) {
-            // literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
-            // pre-zeroed output): a whole dword leaves as one store once the output position has moved past it
-            const uint32_t sym = e & 511u;
-            const bool put = active && sym < 256u && o < out_size;  // (an idle or stopped lane "puts" symbol 0: nothing)
+            // Literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
+            // pre-zeroed output); the dword leaves once the output position has moved to another one.  Every token takes part
+            // -- a run, or the zero entry of an idle lane, just contributes a zero byte -- so there is nothing to select.
+            // (An active lane has o - o0 < max_out = out_size - o0: a literal lands inside the block.)
             const uint32_t dw = o >> 2;
-            const bool newdw = put && dw != cur_dw;
-            const bool fl = newdw && acc != 0u;
+            const bool fl = dw != cur_dw;
             if (any_lane(fl)) {
-                if (fl) flush_dword(out, cur_dw, acc);
+                if (fl && acc) flush_dword(out, cur_dw, acc);
             }
-            acc = newdw ? 0u : acc;
-            cur_dw = newdw ? dw : cur_dw;
-            acc |= put ? sym << ((o & 3u) * 8u) : 0u;
+            acc = fl ? 0u : acc;
+            cur_dw = dw;
+            acc |= (e & 0xFFu) << ((o & 3u) * 8u);
         }
         o += zb + extra;
         bp += len + eb;
