@@ -51,8 +51,15 @@ __device__ __forceinline__ uint32_t run_ending_at(uint32_t i, uint32_t lits, uin
     return m ? i - (31u - (uint32_t)__clz((int)m)) : i + 1u + zb;
 }
 
+// full kRunCap tokens in a run of R <= 65536 zeros.  Almost never any: the three compares sit behind one wave-wide test.
+__device__ __forceinline__ uint32_t run_caps(uint32_t R) {
+    uint32_t q = 0;
+    if (__builtin_amdgcn_ballot_w64(R >= kRunCap)) q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    return q;
+}
+
 __device__ __forceinline__ void hist_run(uint32_t* h, const uint32_t* runcls, uint32_t R) {
-    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t q = run_caps(R);
     const uint32_t rem = R - q * kRunCap;
     if (q) atomicAdd(&h[260], q);
     if (rem) atomicAdd(&h[runcls[min(rem, kRunClsEntries - 1u)] & 0xFFFu], 1u);
@@ -60,7 +67,7 @@ __device__ __forceinline__ void hist_run(uint32_t* h, const uint32_t* runcls, ui
 
 // stream bits of the tokens of a zero run
 __device__ __forceinline__ uint32_t run_bits_tab(const uint2* tab, const uint32_t* runcls, uint32_t R) {
-    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t q = run_caps(R);
     const uint32_t rem = R - q * kRunCap;
     uint32_t bits = q ? q * (tab[260].y + 14u) : 0u;
     if (rem) {
@@ -80,7 +87,7 @@ __device__ __forceinline__ void run_token(const uint2* tab, const uint32_t* runc
 
 // OR the tokens of a zero run into the image at bit `pos`; returns the bits written
 __device__ __forceinline__ uint32_t emit_run(uint32_t* stage, const uint2* tab, const uint32_t* runcls, uint32_t pos, uint32_t R) {
-    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t q = run_caps(R);
     const uint32_t rem = R - q * kRunCap;
     uint32_t done = 0;
     if (q) {
@@ -403,7 +410,7 @@ __device__ __forceinline__ void hist_row_sparse(const uint32_t (&w)[4], const Ro
 
 // one entry per lane (R zeros, then the literal unless lit == kNoLit; R = 0 and no literal: nothing), in lane order
 __device__ __forceinline__ void emit_entries(uint32_t R, uint32_t lit, const uint2* tab, const uint32_t* runcls, uint32_t* stage, uint32_t& base) {
-    const uint32_t q = (R >= kRunCap) + (R >= 2 * kRunCap) + (R >= 3 * kRunCap);
+    const uint32_t q = run_caps(R);
     const uint32_t rem = R - q * kRunCap;
     uint64_t rv = 0;
     uint32_t rl = 0;
