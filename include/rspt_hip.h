@@ -115,6 +115,16 @@ int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian);
 void* rspt_hip_host_alloc(size_t bytes);
 void rspt_hip_host_free(void* p);
 
+/* A sequence of blocks from host memory: what the reference's harness does one compress() call at a time
+ * (rspt_test.cpp:139-175, the loop over a recording's blocks).  nblocks consecutive blocks at src_host
+ * (rspt_hip_block_bytes apart); stream i goes to dst_host + i * dst_stride, its length to dst_len[i]; the nb
+ * state moves from block to block as in repeated compress() calls.  Chunks of blocks pass through
+ * upload | compress | download on three HIP streams, so a long sequence runs at the rate of the slowest
+ * stage (the upload over PCIe when src_host is page-locked) instead of at the sum of the three.  Blocking.
+ * A stream that does not fit dst_stride: dst_len[i] = the size it needs, nothing copied for it, and the call
+ * returns RSPT_HIP_ERR_DST_TOO_SMALL after finishing the others. */
+int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len);
+
 /* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
 
 /* Grow the workspace so that up to max_blocks blocks can go through one

@@ -25,6 +25,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
+    "rspt_hip_compress_many",
 ]
 
 _u8p = C.POINTER(C.c_uint8)
@@ -71,6 +72,8 @@ def lib():
     L.rspt_hip_packer_destroy.restype, L.rspt_hip_packer_destroy.argtypes = None, [C.c_void_p]
     L.rspt_hip_compress.restype, L.rspt_hip_compress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _szp]
     L.rspt_hip_decompress.restype, L.rspt_hip_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
+    L.rspt_hip_compress_many.restype = C.c_int
+    L.rspt_hip_compress_many.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
     L.rspt_hip_max_compressed_size.restype, L.rspt_hip_max_compressed_size.argtypes = C.c_size_t, [C.c_void_p]
     L.rspt_hip_block_bytes.restype, L.rspt_hip_block_bytes.argtypes = C.c_size_t, [C.c_void_p]
     L.rspt_hip_current_nb.restype, L.rspt_hip_current_nb.argtypes = C.c_uint, [C.c_void_p]
@@ -160,6 +163,17 @@ class SignalPacker:
         n = C.c_size_t(0)
         self._check("rspt_hip_compress", self._L.rspt_hip_compress(self._h, src.ctypes.data, out.ctypes.data, out.size, C.byref(n)))
         return n.value
+
+    def compress_many(self, src, out, raise_on_small=True):
+        """a sequence of blocks from host memory through the upload | compress | download pipeline (rspt_hip_compress_many):
+        src = uint8 array of n * block_bytes, out = uint8 array [n, stride] -> array of the n stream lengths"""
+        n = src.size // self.block_bytes
+        assert src.size == n * self.block_bytes and out.ndim == 2 and out.shape[0] == n
+        lens = (C.c_size_t * n)()
+        rc = self._L.rspt_hip_compress_many(self._h, src.ctypes.data, n, out.ctypes.data, out.strides[0], lens)
+        if rc != -5 or raise_on_small:  # RSPT_HIP_ERR_DST_TOO_SMALL: the lengths say which streams
+            self._check("rspt_hip_compress_many", rc)
+        return np.array(lens[:], dtype=np.int64)
 
     def decompress_into(self, stream, out):
         n = C.c_size_t(0)

@@ -170,6 +170,14 @@ struct rspt_hip_packer {
     uint8_t* h_dst = nullptr;  // device
     uint64_t* h_size = nullptr;
     size_t h_dst_cap = 0;
+    // rspt_hip_compress_many: two slots of a chunk of blocks each
+    uint8_t* m_src[2] = {nullptr, nullptr};   // device
+    uint8_t* m_dst[2] = {nullptr, nullptr};   // device
+    uint64_t* m_sizes[2] = {nullptr, nullptr};  // device
+    uint64_t* m_hsizes = nullptr;             // page-locked host, 2 x chunk
+    size_t m_chunk = 0, m_stride = 0;
+    hipStream_t m_up = nullptr, m_down = nullptr;
+    hipEvent_t m_ev_up[2] = {}, m_ev_comp[2] = {}, m_ev_down[2] = {};
 
     // tile geometry for the front end
     uint32_t T = 0, in_lds = 0;  // k_tile_planar: tile staged in LDS
@@ -657,6 +665,17 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->m_src[i]);
+        hipFree(p->m_dst[i]);
+        hipFree(p->m_sizes[i]);
+        if (p->m_ev_up[i]) hipEventDestroy(p->m_ev_up[i]);
+        if (p->m_ev_comp[i]) hipEventDestroy(p->m_ev_comp[i]);
+        if (p->m_ev_down[i]) hipEventDestroy(p->m_ev_down[i]);
+    }
+    if (p->m_hsizes) hipHostFree(p->m_hsizes);
+    if (p->m_up) hipStreamDestroy(p->m_up);
+    if (p->m_down) hipStreamDestroy(p->m_down);
     hipFree(p->swapbuf);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
@@ -979,6 +998,88 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
     HIPCHK(p, hipStreamSynchronize(p->stream));
     *dst_len = (size_t)sz;
     return RSPT_HIP_OK;
+}
+
+static int ensure_many(rspt_hip_packer* p) {
+    if (p->m_chunk) return RSPT_HIP_OK;
+    // ~64 MiB of samples per chunk: long enough copies for the DMA engines, short enough that the pipeline fills quickly
+    size_t chunk = (64ull << 20) / p->g.block_bytes;
+    chunk = chunk < 1 ? 1 : chunk > 64 ? 64 : chunk;
+    const size_t stride = (rspt_hip_max_compressed_size(p) + 255) & ~(size_t)255;
+    bool ok = true;
+    for (int i = 0; i < 2; ++i) {
+        ok &= hipMalloc(&p->m_src[i], chunk * p->g.block_bytes + 64) == hipSuccess;
+        ok &= hipMalloc(&p->m_dst[i], chunk * stride) == hipSuccess;
+        ok &= hipMalloc(&p->m_sizes[i], chunk * sizeof(uint64_t)) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&p->m_ev_up[i], hipEventDisableTiming) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&p->m_ev_comp[i], hipEventDisableTiming) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&p->m_ev_down[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok &= hipHostMalloc((void**)&p->m_hsizes, 2 * chunk * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    ok &= hipStreamCreateWithFlags(&p->m_up, hipStreamNonBlocking) == hipSuccess;
+    ok &= hipStreamCreateWithFlags(&p->m_down, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) return RSPT_HIP_ERR_ALLOC;
+    p->m_chunk = chunk;
+    p->m_stride = stride;
+    return rspt_hip_reserve(p, chunk);
+}
+
+int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len) {
+    if (!p || !src_host || !dst_host || !dst_len || nblocks == 0) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    int rc = ensure_many(p);
+    if (rc) return rc;
+    const size_t C = p->m_chunk, bb = p->g.block_bytes;
+    const size_t nchunk = (nblocks + C - 1) / C;
+    const uint8_t* src = (const uint8_t*)src_host;
+    uint8_t* dst = (uint8_t*)dst_host;
+    bool too_small = false;
+    // the streams of chunk k leave for the host (exact lengths: its sizes have to be here first)
+    auto download = [&](size_t k) -> int {
+        const int slot = (int)(k & 1);
+        const size_t first = k * C, cnt = nblocks - first < C ? nblocks - first : C;
+        HIPCHK(p, hipEventSynchronize(p->m_ev_comp[slot]));
+        const uint64_t* hs = p->m_hsizes + (size_t)slot * C;
+        for (size_t i = 0; i < cnt; ++i) {
+            const uint64_t sz = hs[i];
+            if ((sz >> 63) || sz > dst_stride) {  // flagged by the device (did not fit the staging stride), or too long for the caller's
+                dst_len[first + i] = (sz >> 63) ? 0 : (size_t)sz;
+                too_small = true;
+                continue;
+            }
+            dst_len[first + i] = (size_t)sz;
+            HIPCHK(p, hipMemcpyAsync(dst + (first + i) * dst_stride, p->m_dst[slot] + i * p->m_stride, (size_t)sz, hipMemcpyDeviceToHost, p->m_down));
+        }
+        HIPCHK(p, hipEventRecord(p->m_ev_down[slot], p->m_down));
+        return RSPT_HIP_OK;
+    };
+    for (size_t k = 0; k < nchunk; ++k) {
+        const int slot = (int)(k & 1);
+        const size_t first = k * C, cnt = nblocks - first < C ? nblocks - first : C;
+        if (k >= 2) {
+            HIPCHK(p, hipStreamWaitEvent(p->m_up, p->m_ev_comp[slot], 0));     // chunk k-2 has been read out of this slot
+            HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_down[slot], 0));  // ... and its streams have left it
+        }
+        HIPCHK(p, hipMemcpyAsync(p->m_src[slot], src + first * bb, cnt * bb, hipMemcpyHostToDevice, p->m_up));
+        HIPCHK(p, hipEventRecord(p->m_ev_up[slot], p->m_up));
+        HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_up[slot], 0));
+        rc = rspt_hip_compress_batch_dev(p, p->m_src[slot], cnt, p->m_dst[slot], p->m_stride, p->m_sizes[slot], (void*)p->stream);
+        if (rc) return rc;
+        HIPCHK(p, hipMemcpyAsync(p->m_hsizes + (size_t)slot * C, p->m_sizes[slot], cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(p, hipEventRecord(p->m_ev_comp[slot], p->stream));
+        if (k >= 1) {
+            rc = download(k - 1);
+            if (rc) return rc;
+        }
+    }
+    rc = download(nchunk - 1);
+    if (rc) return rc;
+    uint32_t nb_now = 0;
+    HIPCHK(p, hipMemcpyAsync(&nb_now, p->nb_state, sizeof(nb_now), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(p, hipStreamSynchronize(p->stream));
+    HIPCHK(p, hipStreamSynchronize(p->m_down));
+    if (nb_now >= 1 && nb_now <= 4) p->nb_host = nb_now;
+    return too_small ? RSPT_HIP_ERR_DST_TOO_SMALL : RSPT_HIP_OK;
 }
 
 static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,

@@ -98,6 +98,46 @@ def test_host_api_with_page_locked_buffers(api, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_compress_many_equals_a_loop_of_compress_calls(api, orc, pinned):
+    """rspt_hip_compress_many: 150 blocks through the upload | compress | download pipeline (several chunks and a tail; the
+    amplitudes step up in the middle, so nb escalates inside a chunk) == the oracle's packer fed the same blocks one by one"""
+    nch, ns, bps, n = 8, 2048, 4, 150
+    blocks = [cases._rand_native(nch, ns, bps, 4000 + i, 2000 if i < 70 else 1 << 27, walk=bool(i & 1)) for i in range(n)]
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 2)
+    want = [po.compress(b) for b in blocks]
+    pk = api.new_xdelta_hzr(bps, nch, ns, 2)
+    stride = (pk.max_compressed_size + 63) // 64 * 64
+    if pinned:
+        hs, hd = api.HostBuffer(n * pk.block_bytes), api.HostBuffer(n * stride)
+        src, out = hs.a, hd.a.reshape(n, stride)
+    else:
+        src, out = np.empty(n * pk.block_bytes, dtype=np.uint8), np.empty((n, stride), dtype=np.uint8)
+    src[:] = np.concatenate(blocks)
+    lens = pk.compress_many(src, out)
+    for i in range(n):
+        assert lens[i] == len(want[i]) and out[i, : lens[i]].tobytes() == want[i], i
+    assert pk.nb == orc.packer_nb(po) > 2
+    # a destination stride too short for some streams: those report the size they need, the others arrive
+    short = int(np.median(lens))
+    out2 = np.zeros((n, short), dtype=np.uint8)
+    pk2 = api.new_xdelta_hzr(bps, nch, ns, 2)
+    lens2 = pk2.compress_many(src, out2, raise_on_small=False)
+    assert (lens2 == lens).all()
+    for i in range(n):
+        if lens[i] <= short:
+            assert out2[i, : lens[i]].tobytes() == want[i], i
+    with pytest.raises(api.RsptHipError) as e:
+        pk2.compress_many(src, out2)
+    assert e.value.status == -5
+    pk.close()
+    pk2.close()
+    if pinned:
+        hs.close()
+        hd.close()
+
+
+@pytest.mark.gpu
 def test_cxx_factories_follow_the_device_setting(api, tmp_path):
     """RSPT_HIP_DEVICE / rspt_cxx_set_device place the C++ factories' packers; the sharding example runs on every visible GPU"""
     from rspt_amd import build

@@ -31,3 +31,22 @@ rate("pageable", x.copy(), np.empty(2 * x.size, dtype=np.uint8), np.empty(x.size
 hs, hd, hb = api.HostBuffer(x.size), api.HostBuffer(2 * x.size), api.HostBuffer(x.size)
 hs.a[:] = x
 rate("page-locked", hs.a, hd.a, hb.a)
+
+
+def rate_many(label, src, out, n):
+    pk.compress_many(src, out)
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 3.0:
+        lens = pk.compress_many(src, out); k += 1
+    dt = time.perf_counter() - t0
+    print("%-12s compress_many, %d blocks per call: %8.1f MSamples/s (%.3f ms per 16 MiB block, %.1f GB/s of samples uploaded)"
+          % (label, n, k * n * nch * ns / dt / 1e6, dt / k / n * 1e3, k * n * x.size / dt / 1e9))
+
+
+n = 32
+stride = (pk.max_compressed_size + 255) // 256 * 256
+xs = np.concatenate([synth.synth_native(nch, ns, block_index=i).numpy().reshape(-1) for i in range(n)])
+rate_many("pageable", xs, np.empty((n, stride), dtype=np.uint8), n)
+hs2, hd2 = api.HostBuffer(xs.size), api.HostBuffer(n * stride)
+hs2.a[:] = xs
+rate_many("page-locked", hs2.a, hd2.a.reshape(n, stride), n)
