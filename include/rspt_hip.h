@@ -115,8 +115,9 @@ int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian);
 void* rspt_hip_host_alloc(size_t bytes);
 void rspt_hip_host_free(void* p);
 
-/* A sequence of blocks from host memory: what the reference's harness does one compress() call at a time
- * (rspt_test.cpp:139-175, the loop over a recording's blocks).  nblocks consecutive blocks at src_host
+/* A sequence of blocks from host memory: what a caller of the reference does one compress() call per block
+ * (the call itself: lib_rspt_test/rspt_test.cpp:66-72; a packer is made for ONE block shape, signal_packer.h:60-72, so a
+ * recording longer than that is a loop of such calls on the same instance).  nblocks consecutive blocks at src_host
  * (rspt_hip_block_bytes apart); stream i goes to dst_host + i * dst_stride, its length to dst_len[i]; the nb
  * state moves from block to block as in repeated compress() calls.  Chunks of blocks pass through
  * upload | compress | download on three HIP streams, so a long sequence runs at the rate of the slowest
