@@ -561,8 +561,67 @@ __device__ __forceinline__ void rotate_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4]
     rc[3] = tc;
 }
 
+// A wave whose four rows are all sparse (the segments of the "medium" blocks: every 4 KiB non-zero, a few literals per row)
+// takes them as ONE queue: two packed scans instead of four, one pass over the entries instead of one per row, and the
+// queue is the segment's entry list as it stands.  Between sparse rows nothing special happens at a row boundary: the zeros
+// in front of a row's first literal are the gap to the entry before it, whichever row that one came from; only entry 0
+// looks outside the segment (rc[0].zb0).  False: too many entries for the queue -- the caller goes row by row.
+__device__ __forceinline__ bool hist_segment_sparse(const uint32_t (&W)[4][4], const RowCtx (&rc)[4], uint32_t in_size, uint32_t* h,
+                                                    const uint32_t* runcls, uint32_t* queue, ListSink& sink) {
+    const uint32_t l = lane_id();
+    uint32_t lits[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lits[r] = lane_lits(W[r]);  // (bytes behind the block end were masked to zero at the load)
+    const uint32_t n01 = (uint32_t)__popc(lits[0]) | ((uint32_t)__popc(lits[1]) << 16);
+    const uint32_t n23 = (uint32_t)__popc(lits[2]) | ((uint32_t)__popc(lits[3]) << 16);
+    const uint32_t inc01 = wave_scan_add(n01), inc23 = wave_scan_add(n23);
+    const uint32_t tot01 = read_lane(inc01, 63), tot23 = read_lane(inc23, 63);
+    const uint32_t last = rc[0].last | rc[1].last | rc[2].last | rc[3].last;  // the block ends in this segment: the run that reaches its end
+    const uint32_t S1 = tot01 & 0xFFFFu, S2 = S1 + (tot01 >> 16), S3 = S2 + (tot23 & 0xFFFFu);
+    const uint32_t T = S3 + (tot23 >> 16) + (last ? 1u : 0u);
+    if (T > kQueueEntries) return false;
+    if (T == 0) return true;  // nothing but zeros, and the block goes on
+    const uint32_t ex01 = inc01 - n01, ex23 = inc23 - n23;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t k = (r == 0 ? 0u : r == 1 ? S1 : r == 2 ? S2 : S3) + (((r < 2 ? ex01 : ex23) >> ((r & 1) * 16)) & 0xFFFFu);
+        uint32_t t = lits[r];
+        const uint32_t pos0 = rc[r].rb + 16u * l;
+        while (t) {
+            const uint32_t i = (uint32_t)__builtin_ctz(t);
+            t &= t - 1;
+            queue[k++] = ((pos0 + i) << 9) | granule_byte_dyn(W[r][0], W[r][1], W[r][2], W[r][3], i);
+        }
+    }
+    if (last && l == 0) queue[T - 1u] = (in_size << 9) | kNoLit;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (sink.n != kListNone && sink.n + T <= kListCap) {
+        for (uint32_t c = l; c < T; c += 64) sink.dst[sink.n + c] = queue[c];
+        sink.n += T;
+    } else {
+        sink.n = kListNone;
+    }
+    const uint32_t before0 = rc[0].rb - rc[0].zb0;
+    for (uint32_t c = 0; c < T; c += 64) {
+        const uint32_t k = c + l;
+        if (k < T) {
+            const uint32_t e = queue[k];
+            const uint32_t before = k ? (queue[k - 1u] >> 9) + 1u : before0;  // position behind the literal before this one
+            const uint32_t R = (e >> 9) - before, lit = e & 0x1FFu;
+            if (R) hist_run(h, runcls, R);
+            if (lit < 256u) atomicAdd(&h[lit], 1u);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the queue is reused by the next block
+    return true;
+}
+
 __device__ __forceinline__ void hist_rows(uint32_t (&W)[4][4], RowCtx (&rc)[4], uint32_t in_size, uint32_t* myhist, const uint32_t* runcls,
                                           uint32_t* queue, ListSink& sink) {
+    if (queue != nullptr && !(row_is_dense(W[0], rc[0]) | row_is_dense(W[1], rc[1]) | row_is_dense(W[2], rc[2]) | row_is_dense(W[3], rc[3]))) {
+        if (hist_segment_sparse(W, rc, in_size, myhist, runcls, queue, sink)) return;
+    }
 #pragma unroll 1
     for (int r = 0; r < 4; ++r) {
         if (row_is_dense(W[0], rc[0])) {
