@@ -137,9 +137,19 @@ struct DenseMasks {
     __device__ __forceinline__ unsigned long long p2(int i) const { return i >= 2 ? Z[i - 2] : i == 1 ? z15s : z14s; }
     __device__ __forceinline__ unsigned long long nx(int i) const { return i <= 14 ? Z[i + 1] : z0n; }
 };
+// "byte i of every lane is zero" as sixteen scalar masks.  The byte select rides on the compare's operand (SDWA): one vector
+// instruction per mask where `v_and` + `v_cmp` took two.  (The trailing s_nop covers the wait states this target wants
+// between a vector write of a scalar register and a vector read of it as a mask; the compiler does not look inside.)
 __device__ __forceinline__ void dense_masks(const uint32_t (&w)[4], const RowCtx& rc, DenseMasks& M) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) M.Z[i] = __ballot(((w[i >> 2] >> ((i & 3) * 8)) & 0xFFu) == 0u);
+    const uint32_t zero = 0;
+#define RSPT_ZB(o, wi, b) "v_cmp_eq_u32_sdwa %" #o ", %" #wi ", %20 src0_sel:BYTE_" #b " src1_sel:DWORD\n\t"
+    asm volatile(RSPT_ZB(0, 16, 0) RSPT_ZB(1, 16, 1) RSPT_ZB(2, 16, 2) RSPT_ZB(3, 16, 3) RSPT_ZB(4, 17, 0) RSPT_ZB(5, 17, 1) RSPT_ZB(6, 17, 2)
+                     RSPT_ZB(7, 17, 3) RSPT_ZB(8, 18, 0) RSPT_ZB(9, 18, 1) RSPT_ZB(10, 18, 2) RSPT_ZB(11, 18, 3) RSPT_ZB(12, 19, 0)
+                         RSPT_ZB(13, 19, 1) RSPT_ZB(14, 19, 2) RSPT_ZB(15, 19, 3) "s_nop 1"
+                 : "=s"(M.Z[0]), "=s"(M.Z[1]), "=s"(M.Z[2]), "=s"(M.Z[3]), "=s"(M.Z[4]), "=s"(M.Z[5]), "=s"(M.Z[6]), "=s"(M.Z[7]), "=s"(M.Z[8]),
+                   "=s"(M.Z[9]), "=s"(M.Z[10]), "=s"(M.Z[11]), "=s"(M.Z[12]), "=s"(M.Z[13]), "=s"(M.Z[14]), "=s"(M.Z[15])
+                 : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(zero));
+#undef RSPT_ZB
     M.z15s = (M.Z[15] << 1) | (rc.zb0 >= 1 ? 1ull : 0ull);
     M.z14s = (M.Z[14] << 1) | (rc.zb0 >= 2 ? 1ull : 0ull);
     M.z0n = (M.Z[0] >> 1) | (rc.last ? 0ull : (1ull << 63));
@@ -202,6 +212,17 @@ __device__ __forceinline__ void hist_row_dense(const uint32_t (&w)[4], const Row
     }
 }
 
+// byte B of w, times 8: the byte select is part of the shift's operand (SDWA)
+__device__ __forceinline__ uint32_t byte_times8(uint32_t w, int B /* constant after unrolling */) {
+    uint32_t r;
+    const uint32_t three = 3;
+    if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(w));
+    else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(w));
+    else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(w));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(w));
+    return r;
+}
+
 // One dense row from lookup to image.  `base` = stream bit at which this row's tokens start.
 __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const RowCtx& rc, const uint2* tab, const uint32_t* runcls, uint32_t* stage,
                                                uint32_t& base) {
@@ -223,10 +244,10 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
             const unsigned long long P2 = M.p2(i);
             const unsigned long long Len2 = A & ~P2, Long = A & P2;
             const unsigned long long Dead = ZZ | Long;
-            uint32_t idx = (w[i >> 2] >> ((i & 3) * 8)) & 0xFFu;
-            idx = lane_bit(Dead) ? 261u : idx;  // {0, 0}
-            idx = lane_bit(Len2) ? 256u : idx;
-            c[e] = tab[idx];
+            uint32_t off = byte_times8(w[i >> 2], i & 3);  // table entries are 8 bytes
+            off = lane_bit(Dead) ? 261u * 8u : off;                    // {0, 0}
+            off = lane_bit(Len2) ? 256u * 8u : off;
+            c[e] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(tab) + off);
             longany |= Long;
             zzprev = ZZ;
         }
