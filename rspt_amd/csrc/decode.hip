@@ -156,19 +156,14 @@ __device__ __forceinline__ uint32_t peek32(const uint32_t* st, uint32_t bp) {
     return (uint32_t)(v >> sh);
 }
 
-// One assembled output dword to memory.  A byte that is zero in `acc` is a zero-run byte (already zero in the output) or
-// belongs to a neighbour chunk (which may be writing it right now): only the non-zero bytes are stored, as one dword when
-// all four are there (the common case in a dense plane), else one by one (an atomic OR of the dword instead was much slower).
-__device__ __forceinline__ void flush_dword(uint8_t* out, uint32_t dw, uint32_t acc) {
-    const bool has_zero_byte = ((acc - 0x01010101u) & ~acc & 0x80808080u) != 0u;
-    if (!has_zero_byte) {
-        reinterpret_cast<uint32_t*>(out)[dw] = acc;
-    } else {
+// One assembled output dword to memory, byte by byte: for the two dwords at the ends of a chunk's output range, which it may
+// share with its neighbours.  A byte that is zero in `acc` is a zero-run byte (already zero in the pre-zeroed output) or a
+// neighbour's (which may be writing it right now): only the non-zero bytes are stored.
+__device__ __forceinline__ void flush_edge_dword(uint8_t* out, uint32_t dw, uint32_t acc) {
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
-            const uint32_t v = (acc >> (8 * q)) & 0xFFu;
-            if (v) out[dw * 4 + q] = (uint8_t)v;
-        }
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t v = (acc >> (8 * q)) & 0xFFu;
+        if (v) out[dw * 4 + q] = (uint8_t)v;
     }
 }
 
@@ -184,20 +179,27 @@ __device__ __forceinline__ uint32_t tok_meta(uint32_t sym) {
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
-template <bool WRITE>
+enum DecMode { kDecScan = 0, kDecCount = 1, kDecWrite = 2 };  // code boundaries only / + bytes produced / + the bytes themselves
+
+template <int MODE>
 __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint32_t limit, uint32_t bit_end, uint32_t& produced, uint8_t* out,
                                               uint32_t o0, uint32_t out_size, uint32_t& err, uint32_t max_out = 0xFFFFFFFFu) {
+    constexpr bool WRITE = MODE == kDecWrite, COUNT = MODE != kDecScan;
     uint32_t o = o0;
-    uint32_t cur_dw = 0xFFFFFFFFu, acc = 0;  // WRITE: aligned output dword being assembled
-    uint32_t lim = limit;                    // 0 once the lane is done for good (its byte budget is spent, or a bad code)
+    // WRITE: the aligned output dword being assembled.  The dword that holds o0 may be shared with the chunk in front (and
+    // the last one with the chunk behind): those two leave byte by byte, every dword in between belongs to this chunk alone
+    // and leaves as one store -- its zero bytes are zero-run bytes, zero in the pre-zeroed output as well.
+    const uint32_t first_dw = o0 >> 2;
+    uint32_t cur_dw = first_dw, acc = 0;
+    uint32_t lim = limit;  // 0 once the lane is done for good (its byte budget is spent, or a bad code)
     for (;;) {
         // (limit <= bit_end: a lane that ran over the payload is past its limit too -- tested once, behind the loop)
         if (WRITE) lim = o - o0 < max_out ? lim : 0u;
         const bool active = bp < lim;
         if (!any_lane(active)) break;
         const uint32_t wi = bp >> 5, sh = bp & 31u;
-        const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1], w2 = d.stage[wi + 2];  // (a done lane reads inside the slack words)
-        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh), hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1];  // (a done lane reads inside the slack words)
+        const uint32_t lo = __builtin_amdgcn_alignbit(w1, w0, sh);
         uint32_t e = d.lut[lo & ((1u << kLutBits) - 1u)];
         e = active ? e : 0u;  // an entry of zero moves nothing: the lanes that are done idle through the rest
         if (any_lane((int32_t)e < 0)) {
@@ -221,28 +223,38 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
             lim = bad ? 0u : lim;
             err |= bad ? 1u : 0u;
         }
-        const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u, zb = (e >> 19) & 511u;
-        const unsigned long long win = ((unsigned long long)hi << 32) | lo;
-        const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
-        if (WRITE) {
-            // Literals gather in the aligned dword they fall into (the bytes of zero runs are zeros there as in the
-            // pre-zeroed output); the dword leaves once the output position has moved to another one.  Every token takes part
-            // -- a run, or the zero entry of an idle lane, just contributes a zero byte -- so there is nothing to select.
-            // (An active lane has o - o0 < max_out = out_size - o0: a literal lands inside the block.)
-            const uint32_t dw = o >> 2;
-            const bool fl = dw != cur_dw;
-            if (any_lane(fl)) {
-                if (fl && acc) flush_dword(out, cur_dw, acc);
+        const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u;
+        if (COUNT) {
+            const uint32_t w2 = d.stage[wi + 2];
+            const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            const unsigned long long win = ((unsigned long long)hi << 32) | lo;
+            const uint32_t zb = (e >> 19) & 511u;
+            const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+            if (WRITE) {
+                // Literals gather in the aligned dword they fall into; the dword leaves once the output position has moved to
+                // another one.  Every token takes part -- a run, or the zero entry of an idle lane, just contributes a zero
+                // byte -- so there is nothing to select.  (An active lane has o - o0 < max_out = out_size - o0: a literal
+                // lands inside the block.)
+                const uint32_t dw = o >> 2;
+                const bool fl = dw != cur_dw;
+                if (any_lane(fl)) {
+                    if (fl) {
+                        if (cur_dw != first_dw)
+                            reinterpret_cast<uint32_t*>(out)[cur_dw] = acc;
+                        else
+                            flush_edge_dword(out, cur_dw, acc);
+                    }
+                }
+                acc = fl ? 0u : acc;
+                cur_dw = dw;
+                acc |= (e & 0xFFu) << ((o & 3u) * 8u);
             }
-            acc = fl ? 0u : acc;
-            cur_dw = dw;
-            acc |= (e & 0xFFu) << ((o & 3u) * 8u);
+            o += zb + extra;
         }
-        o += zb + extra;
         bp += len + eb;
     }
     if (bp > bit_end) err = 1;  // ran over the payload
-    if (WRITE && acc) flush_dword(out, cur_dw, acc);
+    if (WRITE) flush_edge_dword(out, cur_dw, acc);
     produced = o - o0;
     return bp;
 }
@@ -622,7 +634,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     const uint32_t limit = tid + 1 == nchunk ? bit_end : min(bit_end, code0 + (tid + 1) * S);
     uint32_t start = code0 + tid * S, produced = 0, spec_err = 0;
     if (mine) {
-        d.cend[tid] = dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
+        d.cend[tid] = dec_chunk<kDecScan>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);  // boundaries only
     }
 #if defined(RSPT_DIAG) && defined(RSPT_DEC_ONEROUND)  // timing probe, diagnostic builds only
     for (uint32_t round = 0; round < 1; ++round) {
@@ -634,12 +646,13 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
         uint32_t want = start;
         if (mine && tid > 0) want = d.cend[tid - 1];
         __syncthreads();  // everybody has read its predecessor's end before anybody rewrites its own
-        if (mine && want != start) {
+        // round 0 counts every chunk's bytes (the pre-pass found boundaries only); later rounds redo the chunks that moved
+        if (mine && (round == 0 || want != start)) {
+            if (want != start) d.changed = 1;
             start = want;
             spec_err = 0;
             produced = 0;
-            d.cend[tid] = start >= limit ? start : dec_chunk<false>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
-            d.changed = 1;
+            d.cend[tid] = start >= limit ? start : dec_chunk<kDecCount>(d, start, limit, bit_end, produced, nullptr, 0, 0, spec_err);
         }
         __syncthreads();
         if (!d.changed) break;
@@ -657,9 +670,9 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     const uint32_t o0 = pre + incl - mycount;  // exact for every chunk up to the one that holds the end
     uint32_t e2 = 0, p2 = 0;
 #if defined(RSPT_DIAG) && defined(RSPT_DEC_NOWRITE)  // timing probe, diagnostic builds only
-    if (mine && start < limit && o0 < out_size) dec_chunk<false>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+    if (mine && start < limit && o0 < out_size) dec_chunk<kDecCount>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
 #else
-    if (mine && start < limit && o0 < out_size) dec_chunk<true>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+    if (mine && start < limit && o0 < out_size) dec_chunk<kDecWrite>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
 #endif
     // sound iff no bad code was met and exactly out_size bytes came out
     const uint32_t inc2 = wave_scan_add(p2);
