@@ -110,6 +110,31 @@ def test_corrupt_stream_is_reported(api, orc, packer_cases):
     pk.close()
 
 
+def test_bit_flips_never_take_the_decoder_down(api, orc, packer_cases):
+    """48 single-bit flips all over a stream (framing, block headers, tree descriptions, code bits, CRC fields): with
+    block verification on, every one is either reported (RSPT_HIP_ERR_CORRUPT) or decodes to the original bytes (a flip in
+    pad bits); none may hang or fault, and the handle decodes the pristine stream afterwards."""
+    c = packer_cases["ecg12x8192_xdelta"]
+    s = orc.packer("xdelta_hzr", c["bps"], c["nch"], c["ns"], 3).compress(c["data"])
+    pk = api.new_xdelta_hzr(c["bps"], c["nch"], c["ns"], 3)
+    pk.set_verify(True)
+    rng = np.random.default_rng(20260406)
+    reported = 0
+    for pos in rng.integers(0, 8 * len(s), 48):
+        bad = bytearray(s)
+        bad[pos >> 3] ^= 1 << (pos & 7)
+        try:
+            dec, used = pk.decompress(bytes(bad) + bytes(64))
+            assert dec == c["data"].tobytes(), "a damaged stream decoded to other bytes without being reported (bit %d)" % pos
+        except api.RsptHipError as e:
+            assert e.status == -6, (pos, e.status)
+            reported += 1
+    assert reported >= 40  # (nearly every bit of a stream matters)
+    dec, used = pk.decompress(s)
+    assert used == len(s) and dec == c["data"].tobytes()
+    pk.close()
+
+
 def test_batched_decompress(api, orc):
     import torch
 
