@@ -655,10 +655,11 @@ orc_packer* orc_packer_new(int kind, size_t bps, size_t nch, size_t ns, size_t n
         free(p);
         return NULL;
     }
-    /* dct with ns > 8192: the reference's n*n float table is out of reach.  The handle is
-     * still created, without the table: only the *_coeffs entry points work on it (framing around a
-     * transform the caller evaluates in fp64). */
-    const int dct_table = kind == ORC_KIND_DCT && ns <= 8192;
+    /* dct with ns = 2^k > 8192 (and anything past 32768, where the reference's int table index overflows):
+     * the handle is created without the n*n float table, and only the *_coeffs entry points work on it
+     * (framing around a transform the caller evaluates in fp64).  Other sizes up to 32768 get the table,
+     * as the GPU build gives them: 400 MB at ns = 10000. */
+    const int dct_table = kind == ORC_KIND_DCT && (ns <= 8192 || (ns <= 32768 && !is_pow2(ns)));
     p->enc = (int32_t*)calloc(p->n, sizeof(int32_t));
     p->tmp = (int32_t*)calloc(p->ns, sizeof(int32_t));
     p->planes = (uint8_t*)calloc(4 * p->n, 1);

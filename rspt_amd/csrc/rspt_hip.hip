@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -538,11 +539,13 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
         return RSPT_HIP_ERR_UNSUPPORTED;
     }
     if (kind == RSPT_HIP_KIND_DCT) {
-        // n <= 8192: the reference's dense n x n table (bit-exact).  Larger n (where the reference cannot run):
-        // fp64 FFT path, n = 2^k only.  RSPT_DCT_FFT=1 forces the FFT path for small n (cross-check against the table path).
+        // The reference's dense n x n table (bit-exact) for every n it can run itself -- its table index `(2x+1)*i` is an
+        // int (signal_packer_dct.cpp:60-74): n <= 32768 -- except n = 2^k > 8192, which take the fp64 FFT path (PRDN / CR
+        // tolerance) as do the sizes beyond the reference's reach, n = 2^k <= 2^22.  The table is n^2 floats twice over
+        // (8.6 GB at 32768).  RSPT_HIP_DCT_FORCE_FFT forces the FFT path for small n = 2^k (cross-check against the table).
         const bool pow2 = (ns & (ns - 1)) == 0;
-        p->dct_fft = ns > 8192 || (force_fft && pow2 && ns >= 16);
-        if (p->dct_fft && (!pow2 || ns > (1u << 22))) {
+        p->dct_fft = (ns > 8192 && pow2) || (force_fft && pow2 && ns >= 16);
+        if (p->dct_fft ? ns > (1u << 22) : ns > 32768) {
             delete p;
             return RSPT_HIP_ERR_UNSUPPORTED;
         }
@@ -620,24 +623,43 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
             return RSPT_HIP_ERR_LAUNCH;
         }
     } else if (kind == RSPT_HIP_KIND_DCT) {
-        // init_cos_table (signal_packer_dct.cpp:60-74), host libm, same expression and types
+        // init_cos_table (signal_packer_dct.cpp:60-74), host libm, same expression and types.  Built in slabs of rows by
+        // all host threads (10^9 cosines at n = 32768) and uploaded slab by slab; the transposed copy is made on the device.
         const size_t n = ns;
-        std::vector<float> tab(n * n), tabt(n * n);
-        const double PI = 3.14159265358979323846;
-        const double pi_n_2 = PI / ((double)(int)n * 2.0);
-        for (size_t x = 0; x < n; ++x)
-            for (size_t i = 0; i < n; ++i) {
-                const int arg = ((int)x << 1) * (int)i + (int)i;
-                const float v = (float)cos(arg * pi_n_2);
-                tab[x * n + i] = v;
-                tabt[i * n + x] = v;
-            }
         if (hipMalloc(&p->cos_tab, n * n * sizeof(float)) != hipSuccess || hipMalloc(&p->cos_tab_t, n * n * sizeof(float)) != hipSuccess) {
             rspt_hip_packer_destroy(p);
             return RSPT_HIP_ERR_ALLOC;
         }
-        if (hipMemcpy(p->cos_tab, tab.data(), n * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(p->cos_tab_t, tabt.data(), n * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        const double PI = 3.14159265358979323846;
+        const double pi_n_2 = PI / ((double)(int)n * 2.0);
+        const size_t slab = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (n * sizeof(float))));
+        std::vector<float> tab(slab * n);
+        unsigned nthr = std::thread::hardware_concurrency();
+        nthr = nthr < 1 ? 1 : nthr > 32 ? 32 : nthr;
+        for (size_t x0 = 0; x0 < n; x0 += slab) {
+            const size_t nr = std::min(slab, n - x0);
+            auto fill = [&](size_t r0, size_t r1) {
+                for (size_t x = x0 + r0; x < x0 + r1; ++x)
+                    for (size_t i = 0; i < n; ++i) {
+                        const int arg = ((int)x << 1) * (int)i + (int)i;
+                        tab[(x - x0) * n + i] = (float)cos(arg * pi_n_2);
+                    }
+            };
+            if (nr * n < (1u << 20) || nthr == 1) {
+                fill(0, nr);
+            } else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nthr; ++t) th.emplace_back(fill, nr * t / nthr, nr * (t + 1) / nthr);
+                for (auto& t : th) t.join();
+            }
+            if (hipMemcpy(p->cos_tab + x0 * n, tab.data(), nr * n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+                rspt_hip_packer_destroy(p);
+                return RSPT_HIP_ERR_LAUNCH;
+            }
+        }
+        hipLaunchKernelGGL(k_transpose_f32, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, 0, p->cos_tab, p->cos_tab_t,
+                           (uint32_t)n);
+        if (hipGetLastError() != hipSuccess) {
             rspt_hip_packer_destroy(p);
             return RSPT_HIP_ERR_LAUNCH;
         }

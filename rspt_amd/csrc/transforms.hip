@@ -309,6 +309,18 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
     }
 }
 
+// n x n float matrix -> its transpose (the inverse DCT reads the cosine table the other way round), 32 x 32 tiles
+__global__ __launch_bounds__(256) void k_transpose_f32(const float* __restrict__ a, float* __restrict__ t, uint32_t n) {
+    __shared__ float s[32][33];
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;  // 32 x 8
+    const uint32_t x0 = blockIdx.x * 32u, y0 = blockIdx.y * 32u;
+    for (uint32_t r = ty; r < 32u; r += 8u)
+        if (y0 + r < n && x0 + tx < n) s[r][tx] = a[(size_t)(y0 + r) * n + x0 + tx];
+    __syncthreads();
+    for (uint32_t r = ty; r < 32u; r += 8u)
+        if (x0 + r < n && y0 + tx < n) t[(size_t)(x0 + r) * n + y0 + tx] = s[tx][r];
+}
+
 template <bool FORWARD>
 __global__ __launch_bounds__(256) void k_dct(const int32_t* __restrict__ in, Geom g, uint8_t* __restrict__ means,
                                             const float* __restrict__ tab, double scale0, double scale1, float cs0,

@@ -203,6 +203,13 @@ def dct_big_cases():
                  data=np.ascontiguousarray(synth.synth_native(2, 16384, block_index=11, ecg=True).numpy().reshape(-1)))]
 
 
+def dct_dense_big_cases():
+    """dct at ns > 8192 that is NOT a power of two: the reference's own n x n table on the GPU as well (bit-exact), up to the
+    reach of the reference's int table index (ns <= 32768).  The reference's full stream is the fixture."""
+    return [dict(name="synth2x10000_dct", kind="dct", bps=4, nch=2, ns=10000, nb=2,
+                 data=np.ascontiguousarray(synth.synth_native(2, 10000, block_index=12, ecg=True).numpy().reshape(-1)))]
+
+
 # the reference's band-pass (0.4-200 Hz Butterworth @ 2000 Sps, lib_rspt_test/rspt_test.cpp:123-125) and two shorter filters
 # of lib_rspt/filter.h:104-112, as (n = feedback, d = feed-forward)
 IIR_BANDPASS = ([1.00000000000, -3.14332095199, 3.70064088865, -1.97083923944, 0.41351972908],

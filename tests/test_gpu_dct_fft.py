@@ -131,6 +131,26 @@ def test_dct_16384_against_the_reference_stream(api, orc, golden):
         pk.close()
 
 
+def test_dct_dense_table_beyond_8192(api, orc, golden):
+    """ns = 10000 (not a power of two): the reference's dense table on the GPU -- the REAL reference's stream byte for byte,
+    and its decode."""
+    import zlib
+
+    import cases
+
+    for c in cases.dct_dense_big_cases():
+        g = golden["dct_dense_big"][c["name"]]
+        want = bytes.fromhex(g["stream"])
+        pk = api.new_dct(c["bps"], c["nch"], c["ns"])
+        got = pk.compress(c["data"])
+        assert got == want
+        dec, used = pk.decompress(want)
+        assert used == len(want) and zlib.crc32(dec) == g["decoded_crc32"]
+        pk.close()
+
+
 def test_dct_unsupported_sizes(api):
     with pytest.raises(Exception):
-        api.new_dct(4, 1, 8193 + 7)  # > 8192 and not a power of two
+        api.new_dct(4, 1, 32768 + 8)  # beyond the reference's own reach (int table index) and not a power of two
+    with pytest.raises(Exception):
+        api.new_dct(4, 1, 1 << 23)  # the FFT path stops at 2^22

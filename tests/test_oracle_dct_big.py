@@ -1,5 +1,7 @@
 """The fp64 restatement used as the checker for dct at ns > 8192 (oracle.py: dct_big_*) against the real
 reference where the reference can run (ns <= 8192): SURVEY 8(d)'s gate, and in practice identical streams."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -49,3 +51,18 @@ def test_fp64_restatement_equals_reference_at_16384(orc, golden):
         dec, used = orc.dct_big_decompress(want, c["bps"], c["nch"], c["ns"])
         assert used == len(want)
         assert abs(orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"]) - g["prdn"]) <= PRDN_TOL
+
+
+def test_table_restatement_equals_reference_at_10000(orc, golden):
+    """ns = 10000: not a power of two and beyond 8192 -- the GPU build takes the reference's dense table there too (any ns up
+    to the reach of the reference's int table index, 32768).  The C restatement reproduces the REAL reference's stream."""
+    import cases
+
+    for c in cases.dct_dense_big_cases():
+        g = golden["dct_dense_big"][c["name"]]
+        want = bytes.fromhex(g["stream"])
+        po = orc.packer("dct", c["bps"], c["nch"], c["ns"])
+        got = po.compress(c["data"])
+        assert got == want
+        dec, used, _ = po.decompress(want)
+        assert used == len(want) and zlib.crc32(dec) == g["decoded_crc32"]
