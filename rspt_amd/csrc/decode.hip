@@ -575,12 +575,43 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     }
     for (uint32_t i = tid; i < (1u << kLutBits); i += kDecThreads) d.lut[i] = kLutSlow;  // (steps B / C below fill it)
     const uint32_t nn = d.nnode, nleaf = d.nleaf;
-    for (uint32_t i = tid; i < nn; i += kDecThreads) {  // B
-        if (!(d.node[i] & kNodeLeaf)) {
-            const uint32_t want = (uint32_t)t_open[i] - 1u;  // open subtrees once child_a's subtree is read
-            uint32_t j = i + 1;
-            while (j + 1 < nn && (uint32_t)t_open[j] != want) ++j;  // (a complete description always has the match)
-            const uint32_t cb = j + 1;                               // child_b follows child_a's subtree
+    {  // B (nn <= 521 < kDecThreads: node tid).  Most subtrees are small: a few steps alone; the long searches -- the root's
+       // child_a subtree is half the tree -- are then taken one at a time by the whole wave, 64 positions a step.
+        const uint32_t i = tid;
+        const bool isbr = i < nn && !(d.node[min(i, kNodeSlots - 1u)] & kNodeLeaf);
+        const uint32_t want = isbr ? (uint32_t)t_open[i] - 1u : 0u;  // open subtrees once child_a's subtree is read
+        uint32_t j = i + 1;
+        bool found = !isbr;
+        for (int st = 0; st < 6; ++st) {
+            if (!any_lane(!found)) break;
+            if (!found) {
+                if (j + 1 >= nn || (uint32_t)t_open[j] == want)
+                    found = true;
+                else
+                    ++j;
+            }
+        }
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(!found);
+        while (todo) {
+            const uint32_t srcl = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            uint32_t jj = read_lane(j, srcl);
+            const uint32_t ww = read_lane(want, srcl);
+            uint32_t res = jj;
+            for (;;) {  // (position nn - 1 always ends the search: a complete description has the match before it)
+                const uint32_t pz = jj + l;
+                const bool hit = pz + 1 >= nn || (uint32_t)t_open[min(pz, kNodeSlots - 1u)] == ww;
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+                if (hm) {
+                    res = jj + (uint32_t)__builtin_ctzll(hm);
+                    break;
+                }
+                jj += 64;
+            }
+            if (l == srcl) j = res;
+        }
+        if (isbr) {
+            const uint32_t cb = j + 1;  // child_b follows child_a's subtree
             d.node[i] = cb;
             t_par[i + 1] = (uint16_t)i;
             t_par[cb < nn ? cb : i + 1] = (uint16_t)(i | 0x8000u);
@@ -589,18 +620,14 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     __syncthreads();
     uint32_t deep = 0;
     for (uint32_t i = tid; i < nn; i += kDecThreads) {  // C
-        uint32_t depth = 0, cur = i;
+        // one walk to the root: the decisions come deepest first, so shifting them in from the right leaves the root's at
+        // bit 0 -- the code as the stream has it (root first, LSB first).  (Depths beyond 32 are refused below.)
+        uint32_t depth = 0, cur = i, code = 0;
         while (cur != 0 && depth < 40) {
-            cur = t_par[cur] & 0x7FFFu;
-            ++depth;
-        }
-        uint32_t code = 0, dd = depth;
-        cur = i;
-        while (cur != 0 && dd > 0 && dd <= 32) {
             const uint32_t pw = t_par[cur];
-            --dd;
-            code |= (pw >> 15) << dd;  // code bit at position = depth of the decision (root first, LSB first)
+            code = (code << 1) | (pw >> 15);
             cur = pw & 0x7FFFu;
+            ++depth;
         }
         const uint32_t w_node = d.node[i];
         if (w_node & kNodeLeaf) {
