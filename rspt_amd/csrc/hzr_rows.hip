@@ -785,6 +785,7 @@ struct EncRowsLds {
     uint32_t wsum[kEncWaves];
     uint32_t crc_out;
     uint32_t slot;
+    uint32_t zero_word;          // stays 0: what the CRC reads in front of the image (word -1)
     uint32_t stage[kStagePhys];  // X || payload (+ read slack); light blocks queue sparse-row entries in its tail
 };
 static_assert(sizeof(EncRowsLds) <= 80 * 1024, "two workgroups per CU");
@@ -915,20 +916,29 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
         const int32_t Lv = (int32_t)L + 4;
         const uint32_t nvw = (uint32_t)(Lv + 3) >> 2;
         const uint32_t K = (nvw + kEncThreads - 1) / kEncThreads;  // steps of the fullest lane (block-uniform)
-        auto vword = [&](uint32_t r) -> uint32_t {  // bytes [Lv - 4(r+1), Lv - 4r) of V; bytes in front of V are zero
-            const int32_t lo = Lv - 4 * (int32_t)(r + 1);
-            const int32_t a = lo >> 2;  // arithmetic: floor
-            const uint32_t w_lo = a >= 0 ? d.stage[a] : 0u, w_hi = d.stage[a + 1];
-            return __builtin_amdgcn_alignbyte(w_hi, w_lo, (uint32_t)lo & 3u);
+        // Virtual word r = bytes [Lv - 4(r+1), Lv - 4r) of V = image words a and a + 1 joined at byte (Lv & 3), a =
+        // (Lv >> 2) - 1 - r; bytes in front of V are zero (a = -1 is the zero word in front of the image).  The byte offset
+        // is the same for every word of the block, and only a lane's TOP word may be missing: one test, before the loop.
+        const uint32_t sh = (uint32_t)Lv & 3u;
+        const uint32_t* img = &d.zero_word + 1;  // img[-1] = 0, img[i] = stage[i]
+        auto vword = [&](int32_t a) -> uint32_t { return __builtin_amdgcn_alignbyte(img[a + 1], img[a], sh); };
+        auto times_x4096 = [&](uint32_t c) -> uint32_t {  // * x^(8*4096)
+            return d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];
         };
         uint32_t c = 0;
         if (tid < nvw) {
-            for (uint32_t kk = K - 1; kk >= 1; --kk) {
-                const uint32_t r = tid + kEncThreads * kk;
-                if (r < nvw) c ^= vword(r);
-                c = d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];  // * x^(8*4096)
+            int32_t a = (Lv >> 2) - 1 - (int32_t)(tid + kEncThreads * (K - 1u));
+            if (K > 1u) {
+                c = a >= -1 ? vword(max(a, -1)) : 0u;  // (the top word: there for the low lanes only)
+                c = times_x4096(c);
+                for (uint32_t kk = K - 2u; kk >= 1u; --kk) {
+                    a += (int32_t)kEncThreads;
+                    c ^= vword(a);
+                    c = times_x4096(c);
+                }
+                a += (int32_t)kEncThreads;
             }
-            c ^= vword(tid);
+            c ^= vword(a);
         }
         if (__ballot(c != 0)) {  // waves without data skip the shifts
             const uint32_t red = wave_xor_u32(gf_shift4(cc, l, c));    // every lane to the end of the wave's 64 words
@@ -981,6 +991,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
                                                           const uint2* __restrict__ listinfo, unsigned long long* __restrict__ stamps) {
     (&g_e.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
+    if (threadIdx.x == 0) g_e.zero_word = 0;
     const uint32_t n_big = wq->n_big;
     // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
     // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
