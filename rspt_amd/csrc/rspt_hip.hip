@@ -1046,11 +1046,25 @@ static int ensure_many(rspt_hip_packer* p) {
     return rspt_hip_reserve(p, chunk);
 }
 
+static int compress_many_pipeline(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len);
+
 int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len) {
     if (!p || !src_host || !dst_host || !dst_len || nblocks == 0) return RSPT_HIP_ERR_ARG;
     HIPCHK(p, hipSetDevice(p->device));
     int rc = ensure_many(p);
     if (rc) return rc;
+    rc = compress_many_pipeline(p, src_host, nblocks, dst_host, dst_stride, dst_len);
+    if (rc != RSPT_HIP_OK && rc != RSPT_HIP_ERR_DST_TOO_SMALL) {
+        // a failure in the middle: nothing may still be copying from or into the caller's buffers when we return
+        hipStreamSynchronize(p->m_up);
+        hipStreamSynchronize(p->stream);
+        hipStreamSynchronize(p->m_down);
+    }
+    return rc;
+}
+
+static int compress_many_pipeline(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len) {
+    int rc = RSPT_HIP_OK;
     const size_t C = p->m_chunk, bb = p->g.block_bytes;
     const size_t nchunk = (nblocks + C - 1) / C;
     const uint8_t* src = (const uint8_t*)src_host;
