@@ -90,7 +90,8 @@ constexpr uint32_t kKeyMax = 0xFFFFFFFFu;
 
 struct TreeLds {
     uint32_t key[5 * 64];         // leaf keys: count<<10 | (1023 - index); index order = creation order
-    uint32_t lcnt[2 * kNumSym];   // leaves in the subtree of each node
+    uint32_t lcnt[kNumSym];       // leaves in the subtree of each node, two u16 counts per word (LDS per wave decides how many
+                                  // trees a CU builds at once, and the merge loop is a chain of dependent reductions)
     uint32_t up[2 * kNumSym];     // parent | isB<<10 | sibling<<11 (sibling = child_a, kept for child_b only)
     uint16_t leafsym[kSymStride];
     uint32_t tdesc[kTdescWords];
@@ -236,7 +237,7 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
 
     // ---- node arrays -------------------------------------------------------
     for (uint32_t i = l; i < 5 * 64; i += 64) t.key[i] = kKeyMax;
-    for (uint32_t i = l; i < 2u * kNumSym; i += 64) t.lcnt[i] = i < S ? 1u : 0u;
+    for (uint32_t i = l; i < (uint32_t)kNumSym; i += 64) t.lcnt[i] = (2u * i < S ? 1u : 0u) | (2u * i + 1u < S ? 1u << 16 : 0u);
     for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) t.tdesc[i] = 0;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
@@ -269,7 +270,7 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
         uint32_t cur = i, guard = 0;
         while (cur != root && guard++ < 64) {  // depth <= 22 for <= 65536 tokens; the bound only guards against a corrupted link
             cur = t.up[cur] & 1023u;
-            atomicAdd(&t.lcnt[cur], 1u);
+            atomicAdd(&t.lcnt[cur >> 1], 1u << ((cur & 1u) * 16u));
         }
     }
     __threadfence_block();
@@ -285,7 +286,7 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
             const uint32_t u = t.up[cur];
             const uint32_t is_b = (u >> 10) & 1u;
             code = (code << 1) | is_b;
-            off += is_b ? 11u * t.lcnt[u >> 11] : 1u;  // '0' of the branch (+ all of child_a's subtree: 1 + 11 L - 1)
+            off += is_b ? 11u * ((t.lcnt[u >> 12] >> (((u >> 11) & 1u) * 16u)) & 0xFFFFu) : 1u;  // '0' of the branch (+ all of child_a's subtree: 1 + 11 L - 1)
             ++len;
             cur = u & 1023u;
         }
@@ -368,17 +369,18 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
     __builtin_amdgcn_wave_barrier();
 
     // ---- stream bit at which the tokens of each 4 KiB segment start (k_hist's per-segment histograms x code lengths) ----
-    // lane l: segment l / 4, quarter l % 4 of its 132 u16 pairs
+    // lane l: segment l / 4, every fourth of its 132 u16 pairs from pair l % 4 on (the four lanes of a segment read 16
+    // consecutive bytes: a wave load touches 16 lines, not 64)
     {
         const uint32_t seg = l >> 2, part = l & 3u;
-        const uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2) + seg * (kSymStride / 2) + part * 33u;
+        const uint32_t* sh = seghist + (size_t)hb * (kSegHistStride / 2) + seg * (kSymStride / 2) + part;
         uint32_t pr[33];
 #pragma unroll
-        for (int i = 0; i < 33; ++i) pr[i] = sh[i];
+        for (int i = 0; i < 33; ++i) pr[i] = sh[4 * i];
         uint32_t acc = 0;
 #pragma unroll
         for (int i = 0; i < 33; ++i) {
-            const uint32_t s0 = 2u * (part * 33u + (uint32_t)i);
+            const uint32_t s0 = 2u * (4u * (uint32_t)i + part);
             // unused symbols have count 0: whatever their cost slots hold is multiplied away
             acc += (pr[i] & 0xFFFFu) * t.key[s0];
             acc += (pr[i] >> 16) * t.key[s0 + 1u];
