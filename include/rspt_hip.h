@@ -126,6 +126,15 @@ void rspt_hip_host_free(void* p);
  * returns RSPT_HIP_ERR_DST_TOO_SMALL after finishing the others. */
 int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len);
 
+/* The inverse: nblocks streams at src_host + i * src_stride (src_stride <= rspt_hip_max_compressed_size rounded up to 256)
+ * -> blocks at dst_host + i * rspt_hip_block_bytes, bytes consumed to consumed[i].  As in decompress() a stream's length is
+ * not needed; where the caller knows it, src_len[i] (may be NULL) bounds what is uploaded of stream i -- with 16 MiB blocks
+ * and a stride sized for the worst case that is a fifth of the bytes.  All streams are decoded with the packer's current nb
+ * (rspt_hip_set_nb), like successive decompress() calls.  Same three-stage pipeline; here the download bounds it.  A stream
+ * that does not decode: consumed[i] = 0 and the call returns RSPT_HIP_ERR_CORRUPT after finishing the others. */
+int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t src_stride, const size_t* src_len, size_t nblocks, void* dst_host,
+                             size_t* consumed);
+
 /* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
 
 /* Grow the workspace so that up to max_blocks blocks can go through one

@@ -25,7 +25,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
-    "rspt_hip_compress_many",
+    "rspt_hip_compress_many", "rspt_hip_decompress_many",
 ]
 
 _u8p = C.POINTER(C.c_uint8)
@@ -74,6 +74,8 @@ def lib():
     L.rspt_hip_decompress.restype, L.rspt_hip_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
     L.rspt_hip_compress_many.restype = C.c_int
     L.rspt_hip_compress_many.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
+    L.rspt_hip_decompress_many.restype = C.c_int
+    L.rspt_hip_decompress_many.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, _szp, C.c_size_t, C.c_void_p, _szp]
     L.rspt_hip_max_compressed_size.restype, L.rspt_hip_max_compressed_size.argtypes = C.c_size_t, [C.c_void_p]
     L.rspt_hip_block_bytes.restype, L.rspt_hip_block_bytes.argtypes = C.c_size_t, [C.c_void_p]
     L.rspt_hip_current_nb.restype, L.rspt_hip_current_nb.argtypes = C.c_uint, [C.c_void_p]
@@ -174,6 +176,17 @@ class SignalPacker:
         if rc != -5 or raise_on_small:  # RSPT_HIP_ERR_DST_TOO_SMALL: the lengths say which streams
             self._check("rspt_hip_compress_many", rc)
         return np.array(lens[:], dtype=np.int64)
+
+    def decompress_many(self, streams, out, lengths=None):
+        """streams = uint8 array [n, stride] (one stream per row), out = uint8 array of n * block_bytes -> bytes consumed per stream
+        (rspt_hip_decompress_many: upload | decode | download pipeline); lengths (optional): what to upload of each stream"""
+        n = streams.shape[0]
+        assert streams.ndim == 2 and out.size == n * self.block_bytes
+        used = (C.c_size_t * n)()
+        lens = (C.c_size_t * n)(*[int(v) for v in lengths]) if lengths is not None else None
+        self._check("rspt_hip_decompress_many",
+                    self._L.rspt_hip_decompress_many(self._h, streams.ctypes.data, streams.strides[0], lens, n, out.ctypes.data, used))
+        return np.array(used[:], dtype=np.int64)
 
     def decompress_into(self, stream, out):
         n = C.c_size_t(0)

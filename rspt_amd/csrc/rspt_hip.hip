@@ -1136,6 +1136,78 @@ int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, siz
                           stream);
 }
 
+static int decompress_many_pipeline(rspt_hip_packer* p, const void* src_host, size_t src_stride, const size_t* src_len, size_t nblocks, void* dst_host,
+                                    size_t* consumed) {
+    const size_t C = p->m_chunk, bb = p->g.block_bytes;
+    const size_t nchunk = (nblocks + C - 1) / C;
+    const uint8_t* src = (const uint8_t*)src_host;
+    uint8_t* dst = (uint8_t*)dst_host;
+    bool corrupt = false;
+    // the slots are used the other way round: streams go up into m_dst, blocks come back out of m_src
+    auto finish = [&](size_t k) -> int {
+        const int slot = (int)(k & 1);
+        const size_t first = k * C, cnt = nblocks - first < C ? nblocks - first : C;
+        HIPCHK(p, hipEventSynchronize(p->m_ev_comp[slot]));
+        const uint64_t* hs = p->m_hsizes + (size_t)slot * C;
+        for (size_t i = 0; i < cnt; ++i) {
+            const bool bad = (hs[i] >> 63) != 0;
+            consumed[first + i] = bad ? 0 : (size_t)hs[i];
+            corrupt |= bad;
+        }
+        return RSPT_HIP_OK;
+    };
+    for (size_t k = 0; k < nchunk; ++k) {
+        const int slot = (int)(k & 1);
+        const size_t first = k * C, cnt = nblocks - first < C ? nblocks - first : C;
+        if (k >= 2) {
+            HIPCHK(p, hipStreamWaitEvent(p->m_up, p->m_ev_comp[slot], 0));     // chunk k-2 has been decoded out of this slot
+            HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_down[slot], 0));  // ... and its blocks have left it
+        }
+        if (src_len) {
+            for (size_t i = 0; i < cnt; ++i) {
+                const size_t nbytes = src_len[first + i] < src_stride ? src_len[first + i] : src_stride;
+                if (nbytes) HIPCHK(p, hipMemcpyAsync(p->m_dst[slot] + i * p->m_stride, src + (first + i) * src_stride, nbytes, hipMemcpyHostToDevice, p->m_up));
+            }
+        } else {
+            HIPCHK(p, hipMemcpy2DAsync(p->m_dst[slot], p->m_stride, src + first * src_stride, src_stride, src_stride, cnt, hipMemcpyHostToDevice, p->m_up));
+        }
+        HIPCHK(p, hipEventRecord(p->m_ev_up[slot], p->m_up));
+        HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_up[slot], 0));
+        const int rc = rspt_hip_decompress_batch_dev(p, p->m_dst[slot], p->m_stride, cnt, p->m_src[slot], p->m_sizes[slot], (void*)p->stream);
+        if (rc) return rc;
+        HIPCHK(p, hipMemcpyAsync(p->m_hsizes + (size_t)slot * C, p->m_sizes[slot], cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
+        HIPCHK(p, hipEventRecord(p->m_ev_comp[slot], p->stream));
+        // the blocks leave as soon as they are decoded: their size is known beforehand
+        HIPCHK(p, hipStreamWaitEvent(p->m_down, p->m_ev_comp[slot], 0));
+        HIPCHK(p, hipMemcpyAsync(dst + first * bb, p->m_src[slot], cnt * bb, hipMemcpyDeviceToHost, p->m_down));
+        HIPCHK(p, hipEventRecord(p->m_ev_down[slot], p->m_down));
+        if (k >= 1) {
+            const int rf = finish(k - 1);
+            if (rf) return rf;
+        }
+    }
+    const int rf = finish(nchunk - 1);
+    if (rf) return rf;
+    HIPCHK(p, hipStreamSynchronize(p->m_down));
+    return corrupt ? RSPT_HIP_ERR_CORRUPT : RSPT_HIP_OK;
+}
+
+int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t src_stride, const size_t* src_len, size_t nblocks, void* dst_host,
+                             size_t* consumed) {
+    if (!p || !src_host || !dst_host || !consumed || nblocks == 0 || src_stride == 0) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    int rc = ensure_many(p);
+    if (rc) return rc;
+    if (src_stride > p->m_stride) return RSPT_HIP_ERR_ARG;
+    rc = decompress_many_pipeline(p, src_host, src_stride, src_len, nblocks, dst_host, consumed);
+    if (rc != RSPT_HIP_OK && rc != RSPT_HIP_ERR_CORRUPT) {
+        hipStreamSynchronize(p->m_up);
+        hipStreamSynchronize(p->stream);
+        hipStreamSynchronize(p->m_down);
+    }
+    return rc;
+}
+
 static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,
                           void* d_dst, uint64_t* d_consumed, void* stream) {
     if (!p || !d_src || !d_dst || !d_consumed || nblocks == 0) return RSPT_HIP_ERR_ARG;

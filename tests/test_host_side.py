@@ -118,6 +118,20 @@ def test_compress_many_equals_a_loop_of_compress_calls(api, orc, pinned):
     for i in range(n):
         assert lens[i] == len(want[i]) and out[i, : lens[i]].tobytes() == want[i], i
     assert pk.nb == orc.packer_nb(po) > 2
+    # and back: the same pipeline the other way round (every stream with the nb the sequence ended on)
+    back = np.empty(n * pk.block_bytes, dtype=np.uint8)
+    tail = slice(70, n)  # the blocks behind the escalation: written with the final nb, which is what the handle holds now
+    used = pk.decompress_many(out[tail], back[: (n - 70) * pk.block_bytes])
+    assert (used == lens[tail]).all()
+    back[:] = 0
+    used = pk.decompress_many(out[tail], back[: (n - 70) * pk.block_bytes], lengths=lens[tail])  # upload the streams only
+    assert (used == lens[tail]).all()
+    assert back[: (n - 70) * pk.block_bytes].tobytes() == np.concatenate(blocks[70:]).tobytes()
+    damaged = out[tail].copy()
+    damaged[3, 15] = 7  # stream 3: the first hzr block header [len-1:2][crc:4][mode:1] starts at 9 -> invalid encoding mode
+    with pytest.raises(api.RsptHipError) as e:
+        pk.decompress_many(damaged, back[: (n - 70) * pk.block_bytes])
+    assert e.value.status == -6
     # a destination stride too short for some streams: those report the size they need, the others arrive
     short = int(np.median(lens))
     out2 = np.zeros((n, short), dtype=np.uint8)

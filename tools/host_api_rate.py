@@ -34,7 +34,16 @@ rate("page-locked", hs.a, hd.a, hb.a)
 
 
 def rate_many(label, src, out, n):
-    pk.compress_many(src, out)
+    lens = pk.compress_many(src, out)
+    hold = None if label == "pageable" else api.HostBuffer(src.size)  # (kept alive: the array is a view of its memory)
+    back = np.empty(src.size, dtype=np.uint8) if hold is None else hold.a
+    assert (pk.decompress_many(out, back, lengths=lens) == lens).all() and back.tobytes() == src.tobytes()
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 3.0:
+        pk.decompress_many(out, back, lengths=lens); k += 1
+    dt = time.perf_counter() - t0
+    print("%-12s decompress_many, %d blocks per call: %8.1f MSamples/s (%.3f ms per block, %.1f GB/s of samples downloaded)"
+          % (label, n, k * n * nch * ns / dt / 1e6, dt / k / n * 1e3, k * n * x.size / dt / 1e9))
     t0 = time.perf_counter(); k = 0
     while time.perf_counter() - t0 < 3.0:
         lens = pk.compress_many(src, out); k += 1
