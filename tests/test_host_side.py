@@ -152,6 +152,28 @@ def test_compress_many_equals_a_loop_of_compress_calls(api, orc, pinned):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,bps,nch,ns", [("hzr", 2, 5, 3000), ("hadamard", 4, 3, 4096), ("dct", 4, 2, 1000)])
+def test_many_entry_points_for_the_other_packers(api, orc, kind, bps, nch, ns):
+    """compress_many / decompress_many are the per-call entry points in a pipeline, whatever the packer"""
+    n = 9
+    blocks = [cases._rand_native(nch, ns, bps, 5100 + i, 3000, walk=True) for i in range(n)]
+    po = orc.packer(kind, bps, nch, ns)
+    want = [po.compress(b) for b in blocks]
+    pk = api.SignalPacker(kind, bps, nch, ns)
+    stride = (pk.max_compressed_size + 63) // 64 * 64
+    out = np.zeros((n, stride), dtype=np.uint8)
+    lens = pk.compress_many(np.concatenate(blocks), out)
+    for i in range(n):
+        assert out[i, : lens[i]].tobytes() == want[i], (kind, i)
+    back = np.empty(n * pk.block_bytes, dtype=np.uint8)
+    used = pk.decompress_many(out, back, lengths=lens)
+    assert (used == lens).all()
+    for i in range(n):
+        assert back[i * pk.block_bytes : (i + 1) * pk.block_bytes].tobytes() == bytes(po.decompress(want[i])[0]), (kind, i)
+    pk.close()
+
+
+@pytest.mark.gpu
 def test_cxx_factories_follow_the_device_setting(api, tmp_path):
     """RSPT_HIP_DEVICE / rspt_cxx_set_device place the C++ factories' packers; the sharding example runs on every visible GPU"""
     from rspt_amd import build
