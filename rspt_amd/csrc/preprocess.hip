@@ -647,8 +647,13 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             if (turn(rb)) break;
             if (turn(rc)) break;
         }
-        // the ring's last refills are still in flight and their registers are free for reuse from here on: let them land
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The ring's last refills are still in flight: let them land.  All three register sets pass through the wait, so the
+        // allocator cannot hand any of their registers to something else between the loop exit and this point (a value
+        // parked there would be overwritten by the late load: the compiler does not know these loads exist).
+        item_wait<0>(ra);
+        item_wait<0>(rb);
+        item_wait<0>(rc);
+        asm volatile("" ::: "memory");
     }
     // main pass: the last workgroup to get here runs the escalation scan over the blocks (saves a launch and its gap)
     if (ticket) {
