@@ -624,6 +624,9 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         }
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
         if (++tj == t_ipt) {
+            // (nothing of the previous dirty_fetch is in flight here -- t_open waited for it a tile ago; said once more so that it
+            //  holds on every path of the control-flow graph, not only on the feasible ones: tools/check_stream_regs.py)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dq0), "+s"(dq1), "+s"(dq2), "+s"(dq3)::"memory");
             const uint32_t tw_next = skip_untouched(tw + gridDim.x);
             dirty_fetch(tw_next);  // (consumed by t_open, after this tile's store phase)
             t_close();
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         item_wait<0>(ra);
         item_wait<0>(rb);
         item_wait<0>(rc);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dq0), "+s"(dq1), "+s"(dq2), "+s"(dq3));  // (the dirty bits fetched for a tile that never opens)
         asm volatile("" ::: "memory");
     }
     // main pass: the last workgroup to get here runs the escalation scan over the blocks (saves a launch and its gap)

@@ -2,8 +2,9 @@
 
 The streaming front end issues its loads from inline asm and waits for them with explicit counts, behind the compiler's
 back.  That is only sound if the generated code never touches a destination register between the load and
-the wait that covers it -- e.g. through a copy the register allocator inserts.  tools/check_stream_regs.py scans the
-device assembly for exactly that; the headline instantiations must come out clean."""
+the wait that covers it -- e.g. through a copy the register allocator inserts, or by parking another value there after
+the loop.  tools/check_stream_regs.py walks the control-flow graph of the device assembly for exactly that; all twelve
+instantiations must come out clean."""
 import os
 import subprocess
 import sys
@@ -24,15 +25,13 @@ def test_no_register_is_touched_between_a_hand_issued_load_and_its_wait(tmp_path
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_stream_regs.py"), asm], capture_output=True, text=True).stdout
     summary = {}
     for line in out.splitlines():
-        if "hand-issued loads" in line:
+        if "suspicious accesses" in line:
             name, rest = line.split(":", 1)
-            loads, waits, bad = [int(t) for t in rest.replace(",", " ").split() if t.isdigit()]
-            summary[name.strip()] = (loads, waits, bad)
-    # every instantiation was found and carries hand-issued loads and waits
+            states, bad = [int(t) for t in rest.replace(",", " ").split() if t.isdigit()]
+            summary[name.strip()] = (states, bad)
+    # every instantiation (int32 / int24 / int16, xdelta and plain, whole and ragged tiles) was found, its control-flow graph
+    # was walked (hundreds of ring states each) and no instruction touches a register with a hand-issued load in flight
     assert len(summary) == 12, summary
-    assert all(v[0] >= 96 and v[1] >= 4 for v in summary.values()), summary
-    # the scan is linear (no control-flow graph): instantiations whose slow paths are laid out behind the loop can show
-    # false positives, the int32 / int16 xdelta kernels -- the headline path -- are straight enough to come out clean
-    for name, (loads, waits, bad) in summary.items():
-        if "streamILi4ELb1E" in name or "streamILi2ELb1E" in name:
-            assert bad == 0, (name, bad, out[-2000:])
+    assert all(v[0] >= 300 for v in summary.values()), summary
+    for name, (states, bad) in summary.items():
+        assert bad == 0, (name, bad, out[-3000:])
