@@ -617,6 +617,10 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     // one turn of the ring for set R; true when the stream's last tile has been stored
     auto turn = [&](ItemRegs& R) __attribute__((always_inline)) -> bool {
         item_wait<kAhead>(R);
+        // (Nothing of a dirty_fetch is in flight here -- t_open waited for it when the tile was opened.  Said once more, where
+        //  it costs nothing, so that it holds on every path of the control-flow graph and not only on the feasible ones:
+        //  tools/check_stream_regs.py.  In front of the tile switch below the same wait cost 7 us per launch.)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dq0), "+s"(dq1), "+s"(dq2), "+s"(dq3)::"memory");
         const uint32_t q = tid + tj * nthr;
         if (q < t_nitems) {
             if (BPS == 3) stream_fix24<RAGGED>(R, g, m_nch, tc.s0, tc.Tn, lim4_of(tc.b), tc.b + 1 == nblocks && tc.s0 + tc.Tn == g.ns, q);
@@ -624,9 +628,6 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         }
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
         if (++tj == t_ipt) {
-            // (nothing of the previous dirty_fetch is in flight here -- t_open waited for it a tile ago; said once more so that it
-            //  holds on every path of the control-flow graph, not only on the feasible ones: tools/check_stream_regs.py)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(dq0), "+s"(dq1), "+s"(dq2), "+s"(dq3)::"memory");
             const uint32_t tw_next = skip_untouched(tw + gridDim.x);
             dirty_fetch(tw_next);  // (consumed by t_open, after this tile's store phase)
             t_close();
