@@ -777,6 +777,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
     } while (0)
 #endif
 
+constexpr uint32_t kYieldSmallBlocks = 2048;  // k_encode leaves an eighth of its slots to k_encode_small from this many small blocks on
 struct EncRowsLds {
     uint2 tab[kSymStride];  // {code, length} per lookup index; 261..263 = {0, 0} (a byte that ends no token)
     uint32_t crc[4][256];   // multiplication by x^(8*4096) as four byte-indexed lookups (CrcConsts::shift[78])
@@ -993,11 +994,18 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
     if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     if (threadIdx.x == 0) g_e.zero_word = 0;
     const uint32_t n_big = wq->n_big;
+    // The small blocks are encoded beside this kernel (k_encode_small, side stream) -- but two of these workgroups hold every
+    // wave slot of a CU, so the small ones only get in as these retire, and ran on for ~20 us behind the last big block.  When
+    // there are enough small blocks for that to matter an eighth of the grid steps aside from the start: the small-block kernel
+    // then ends well before this one (64-block batch: encode 0.333 + 0.021 behind it -> 0.328 + 0.010; with few small blocks
+    // the full grid is the faster one).  Every workgroup takes the same decision from the same counter.
+    const uint32_t act = wq->n_small >= kYieldSmallBlocks && gridDim.x >= 16u ? gridDim.x - gridDim.x / 8u : gridDim.x;
+    if (blockIdx.x >= act) return;
     // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
     // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)
     for (uint32_t pass = 0;; ++pass) {
         __syncthreads();  // everyone is done with the previous block (and with the slot)
-        if (threadIdx.x == 0) g_e.slot = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(&wq->next_big, 1u);
+        if (threadIdx.x == 0) g_e.slot = pass == 0 ? blockIdx.x : act + atomicAdd(&wq->next_big, 1u);
         __syncthreads();
         const uint32_t i = g_e.slot;
         if (i >= n_big) break;
