@@ -786,9 +786,12 @@ __global__ __launch_bounds__(kSmallWaves * 64) void k_encode_small(uint8_t* __re
                                                                   const BlockMeta* __restrict__ meta, const uint32_t* __restrict__ cw,
                                                                   const uint32_t* __restrict__ tdesc, const uint64_t* __restrict__ out_off,
                                                                   const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
-                                                                  WorkQueues* __restrict__ wq, const uint32_t* __restrict__ small_list, uint32_t ablate) {
+                                                                  WorkQueues* __restrict__ wq, const uint32_t* __restrict__ small_list, uint32_t ablate,
+                                                                  uint32_t* __restrict__ report) {
     __shared__ uint32_t s_crc[4][256];
     __shared__ uint32_t s_slot[kSmallWaves][kSlotWords];
+    // the host reads this (a word of its own memory) before the NEXT batches: a batch without small blocks needs no side stream
+    if (blockIdx.x == 0 && threadIdx.x == 0) *report = wq->n_small;
     for (uint32_t i = threadIdx.x; i < 1024; i += kSmallWaves * 64) (&s_crc[0][0])[i] = (&cc->table[0][0])[i];
     __syncthreads();
     const uint32_t n_small = wq->n_small;

@@ -196,6 +196,7 @@ struct rspt_hip_packer {
     // the small-block encoder runs beside the big one (it fills the CUs the persistent grid frees in its tail)
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t* h_nsmall = nullptr;  // page-locked, device-visible: the small-block count of a recent batch (written by k_encode_small)
 
     // profiling
     bool profiling = false;
@@ -705,6 +706,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
         hipStreamSynchronize(p->side);
         hipStreamDestroy(p->side);
     }
+    if (p->h_nsmall) hipHostFree(p->h_nsmall);
     if (p->ev_fork) hipEventDestroy(p->ev_fork);
     if (p->ev_join) hipEventDestroy(p->ev_join);
     if (p->stream) hipStreamDestroy(p->stream);
@@ -888,21 +890,30 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     HIPCHK(p, hipGetLastError());
 
     stamp(p, ST_ENCODE, st);
-    {
-        // both encoders depend on k_layout only.  The small-block one goes to the side stream: the big one's persistent
-        // workgroups hold every wave slot, so the small blocks start as those retire and fill its tail.
+    if (!p->h_nsmall) {
+        if (hipHostMalloc((void**)&p->h_nsmall, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+        *p->h_nsmall = 0xFFFFFFFFu;  // (unknown yet)
+    }
+    // Both encoders depend on k_layout only.  The small-block one goes to the side stream (the big one yields it room) -- unless the
+    // recent batches of this handle held no small blocks at all: the fork and join of a second stream cost ~10 us, an empty
+    // kernel in line 2.  The guess only decides where the kernel runs.
+    const bool side = *(volatile uint32_t*)p->h_nsmall != 0u;
+    hipStream_t ss = side ? p->side : st;
+    if (side) {
         HIPCHK(p, hipEventRecord(p->ev_fork, st));
         HIPCHK(p, hipStreamWaitEvent(p->side, p->ev_fork, 0));
+    }
+    {
         const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
         const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
-        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, p->side, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc,
-                           p->out_off, p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate);
-        HIPCHK(p, hipEventRecord(p->ev_join, p->side));
+        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, ss, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate, p->h_nsmall);
     }
+    if (side) HIPCHK(p, hipEventRecord(p->ev_join, p->side));
     hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
                        (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo, p->stamps);
     stamp(p, ST_ENCODE_SMALL, st);
-    HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
+    if (side) HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
