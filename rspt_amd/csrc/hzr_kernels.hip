@@ -319,10 +319,12 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
                                                          const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
                                                          uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
                                                          BlockMeta* __restrict__ meta, const uint32_t* __restrict__ seghist,
-                                                         uint32_t* __restrict__ segbase) {
+                                                         uint32_t* __restrict__ segbase, uint32_t* __restrict__ zero_next, uint32_t zero_words) {
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
+    // the other copy of the per-call zero region, for the next call (rspt_hip.hip: zbuf)
+    for (uint32_t i = blockIdx.x * (kTreeWaves * 64u) + threadIdx.x; i < zero_words; i += gridDim.x * (kTreeWaves * 64u)) zero_next[i] = 0;
     // wave -> hzr block, plane-major: all the blocks of plane 0 (the dense, expensive ones) are dispatched first and
     // next to each other, so they spread over every CU; in (b, k, j) order they recur with a period that the
     // dispatcher's round-robin maps onto a quarter of the CUs (profiles/r01_notes.md: placement resonance)

@@ -120,7 +120,13 @@ struct rspt_hip_packer {
     uint32_t* big_list = nullptr;  // [cap*4*nblk] hzr blocks for the workgroup-per-block encoder (filled by k_layout)
     uint32_t* small_list = nullptr;  // [cap*4*nblk] hzr blocks for the wave-per-block encoder
     int num_cu = 256;
-    uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte
+    uint32_t* nzflag = nullptr;    // [cap*4*nblk] set by the front end when an hzr block holds a non-zero byte (= zbuf[set of the last call])
+    // The per-call zero region [nzflag | needmask | work counters | row sums] exists twice: while a call works in one copy its
+    // k_tree zeroes the other for the next call (one store per thread) -- the memset in front of every call was a 9 us launch.
+    uint32_t* zbuf[2] = {nullptr, nullptr};
+    size_t zcap_words = 0;
+    bool zero_ready[2] = {false, false};  // the copy is known to be all zero
+    int zset = 0;                          // the copy the next call works in
     // Clean-block invariant (k_tile_stream's skipped stores): between calls, hzr block j of plane k of block slot b holds
     // zeros everywhere unless its bit in plane_dirty is set (128 bits per plane, bit = j >> dirty_shift).  The streaming
     // front end writes only the 128-byte lines that hold a non-zero byte into a clean block; k_layout sets the bits of
@@ -407,7 +413,9 @@ static void free_workspace(rspt_hip_packer* p) {
     hipFree(p->nbuse);
     hipFree(p->dec_nb);
     p->dec_nb = nullptr;
-    hipFree(p->nzflag);
+    hipFree(p->zbuf[0]);
+    hipFree(p->zbuf[1]);
+    p->zbuf[0] = p->zbuf[1] = nullptr;
     hipFree(p->plane_dirty);
     p->plane_dirty = nullptr;
     hipFree(p->big_list);
@@ -738,7 +746,13 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     ok &= hipMalloc(&p->plane_dirty, max_blocks * kMaxPlanes * 4 * sizeof(uint32_t)) == hipSuccess;
     // one region zeroed per call by a single memset: [nzflag: B*4*nblk][needmask: B][work counters: 16]; the last two are
     // placed per call right behind the part of nzflag in use
-    ok &= hipMalloc(&p->nzflag, (nhb + max_blocks + 32 + 2 * max_blocks * (size_t)g.nch + 2) * sizeof(uint32_t)) == hipSuccess;
+    p->zcap_words = nhb + max_blocks + 32 + 2 * max_blocks * (size_t)g.nch + 2;
+    for (int i = 0; i < 2; ++i) {
+        ok &= hipMalloc(&p->zbuf[i], p->zcap_words * sizeof(uint32_t)) == hipSuccess;
+        p->zero_ready[i] = false;
+    }
+    p->zset = 0;
+    p->nzflag = p->zbuf[0];
     ok &= hipMalloc(&p->big_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->small_list, nhb * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->hist, nhb * kSymStride * sizeof(uint32_t)) == hipSuccess;
@@ -809,6 +823,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     {
         const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
+        p->nzflag = p->zbuf[p->zset];
         p->needmask = p->nzflag + nhb_call;
         p->work_ctr = p->needmask + ((nblocks + 3) & ~(size_t)3);
         size_t zwords = (size_t)((p->work_ctr + 16) - p->nzflag);
@@ -819,7 +834,8 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
             p->row_sum = reinterpret_cast<long long*>(p->nzflag + zwords);
             zwords += 2 * nblocks * (size_t)g.nch;
         }
-        HIPCHK(p, hipMemsetAsync(p->nzflag, 0, zwords * sizeof(uint32_t), st));
+        if (!p->zero_ready[p->zset]) HIPCHK(p, hipMemsetAsync(p->nzflag, 0, zwords * sizeof(uint32_t), st));  // (first call, or after a failed one)
+        p->zero_ready[0] = p->zero_ready[1] = false;  // this copy is in use now; the other one becomes ready once k_tree is launched
     }
     if (p->planes_unknown || p->ablate) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave)
         HIPCHK(p, hipMemsetAsync(p->plane_dirty, 0xFF, p->cap_blocks * kMaxPlanes * 4 * sizeof(uint32_t), st));
@@ -880,8 +896,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     HIPCHK(p, hipGetLastError());  // (a failing launch is reported at its own stage)
 
     stamp(p, ST_TREE, st);
-    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase);
+    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase,
+                       p->zbuf[p->zset ^ 1], (uint32_t)p->zcap_words);
     HIPCHK(p, hipGetLastError());
+    const int zset_next = p->zset ^ 1;
 
     stamp(p, ST_LAYOUT, st);
     WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
@@ -917,6 +935,8 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     stamp(p, ST_COUNT, st);
     if (p->profiling) p->ev_valid = true;
     HIPCHK(p, hipGetLastError());
+    p->zero_ready[zset_next] = true;  // every launch went out: the other copy is zero when the next call starts
+    p->zset = zset_next;
     return RSPT_HIP_OK;
 }
 
