@@ -542,7 +542,7 @@ __device__ __forceinline__ void or_token(uint32_t* stage, uint32_t pos, uint32_t
 }
 
 constexpr uint32_t kLightPayload = 16384;    // bytes: below it the image words from kTokQueueBase on are free (sparse-row queues)
-constexpr uint32_t kTokQueueBase = 9000;     // stage word (> (16384 + 4) / 4 + 24)
+constexpr uint32_t kTokQueueBase = 4200;     // stage word (> (16384 + 4) / 4 + 24)
 
 // byte q of the image (q = 0..3: X, q >= 4: payload byte q-4)
 __device__ __forceinline__ uint32_t stage_byte(const uint32_t* stage, uint32_t q) { return (stage[(q >> 2)] >> ((q & 3u) * 8)) & 0xFFu; }

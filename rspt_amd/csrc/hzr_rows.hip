@@ -22,7 +22,7 @@
 
 namespace rspt {
 
-constexpr uint32_t kQueueEntries = 320;  // entries per wave and row in the sparse-row queue (5 x 64)
+constexpr uint32_t kQueueEntries = 512;  // entries per wave in the sparse-row queue (8 x 64)
 static_assert(kTokQueueBase + kEncWaves * kQueueEntries <= kStageWords, "emit-phase queues sit in the image tail");
 
 // trailing (highest-address) zero bytes of a granule that is not all zero
