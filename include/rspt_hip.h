@@ -152,7 +152,15 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks);
  *   stream     hipStream_t (as void*) to enqueue on; NULL is the HIP null
  *              stream, as everywhere in HIP.  rspt_hip_stream() returns the
  *              handle's own stream for callers that want that one.
- * Asynchronous: returns after enqueueing. */
+ * Asynchronous: returns after enqueueing.
+ * Ordering contract of a handle: it is ONE packer instance (one workspace, one nb state), so successive batch calls on it
+ * must be stream-ordered -- the same `stream` for all of them, or each call ordered behind the previous one by an event.
+ * (Inside, the per-call scratch that must start from zero exists twice and the kernels of call i zero the copy that call
+ * i+1 works in; the small-block encoder runs on a side stream of the handle, forked from and joined to `stream` inside the
+ * call.)  Two calls racing on different streams would share planes, counters and that zeroing.  One host word is read
+ * without synchronisation, by design: the small-block count a RECENT batch left in page-locked memory only decides whether
+ * the side stream is used at all (a batch shape without small blocks skips the fork/join); a stale value costs a few
+ * microseconds, never correctness. */
 int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nblocks, void* d_dst, size_t dst_stride,
                                 uint64_t* d_sizes, void* stream);
 

@@ -56,6 +56,9 @@ def lib():
                                "before launching ranks" % path)
         if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
             path = _build.build()
+        elif os.path.exists(path):  # built from other sources than the ones beside it, and no compiler to fix that: never run it silently
+            raise RuntimeError("rspt_amd: %s does not match its sources (fingerprint %s) and there is no hipcc here to rebuild it"
+                               % (path, _build.STAMP))
     if not os.path.exists(path):
         raise RuntimeError("rspt_amd: %s is missing and cannot be built here; there is no CPU fallback" % path)
     # One HIP runtime per process: torch ships its own libamdhip64 and the batch entry points take torch
@@ -260,12 +263,14 @@ class SignalPacker:
         if int(head[0]) != 0x4B43415054505352:
             raise ValueError("not an RSPTPACK container")
         nblocks = int(head[1])
+        plen = int(nbytes) if nbytes is not None else d_packed.numel()
+        if nblocks == 0 or nblocks > 65535 or plen < 32 or nblocks > (plen - 32) // 16:  # (nothing is sized from an untrusted count)
+            raise RsptHipError("rspt_hip_decompress_packed_dev", -6 if 0 < nblocks <= 65535 else -1)
         if d_out is None:
             d_out = torch.empty((nblocks, self.block_bytes), dtype=torch.uint8, device=d_packed.device)
         if d_consumed is None:
             d_consumed = torch.empty(nblocks, dtype=torch.int64, device=d_packed.device)
         st = stream if stream is not None else torch.cuda.current_stream(d_packed.device).cuda_stream
-        plen = int(nbytes) if nbytes is not None else d_packed.numel()
         rc = self._L.rspt_hip_decompress_packed_dev(self._h, d_packed.data_ptr(), plen, nblocks, d_out.data_ptr(), d_consumed.data_ptr(), st)
         self._check("rspt_hip_decompress_packed_dev", rc)
         return d_out, d_consumed

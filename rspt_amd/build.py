@@ -39,6 +39,8 @@ def stale():
 
 
 def build(force=False, verbose=False):
+    if "-DRSPT_DIAG" in os.environ.get("RSPT_EXTRA_FLAGS", "").split():
+        return build_diag(verbose)
     if not force and not stale():
         return LIB
     with open(LIB + ".lock", "w") as lk:
@@ -63,6 +65,20 @@ def build(force=False, verbose=False):
     return LIB
 
 
+DIAG_LIB = os.path.join(HERE, "librspt_hip_diag.so")
+
+
+def build_diag(verbose=False):
+    """The diagnostic build (-DRSPT_DIAG: timing probes that skip work, tuning knobs from the environment) never replaces the
+    product library: it goes to librspt_hip_diag.so, which is only ever loaded through RSPT_HIP_LIB."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = [f for f in os.environ.get("RSPT_EXTRA_FLAGS", "").split() if f != "-DRSPT_DIAG"]
+    cmd = [hipcc] + FLAGS + ["-DRSPT_DIAG"] + flags + ["-o", DIAG_LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DIAG_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
-    print(LIB)
+    print(build_diag(verbose=True) if "--diag" in sys.argv else build(force="--force" in sys.argv, verbose=True))

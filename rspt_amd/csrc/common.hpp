@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 // Diagnostics (timing probes that skip work, tuning knobs read from the environment, in-kernel time stamps) exist only in
-// builds with -DRSPT_DIAG (tools/: "RSPT_EXTRA_FLAGS=-DRSPT_DIAG python -m rspt_amd.build" into a separate library).  In the
+// builds with -DRSPT_DIAG (`python -m rspt_amd.build --diag` -> rspt_amd/librspt_hip_diag.so, loaded only via RSPT_HIP_LIB).  In the
 // product library the probe word is the constant 0: every probe branch folds away and no environment variable changes a result.
 #ifdef RSPT_DIAG
 #define RSPT_DIAG_ONLY(x) (x)

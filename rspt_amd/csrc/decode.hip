@@ -55,7 +55,9 @@ __global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride
         const uint64_t* head = pidx - 4;  // magic, nblocks, payload bytes, nb
         const uint64_t payload = head[2];
         const uint64_t off = pidx[2 * b], lw = pidx[2 * b + 1], len = lw & kIdxLenMask;
-        if (head[0] != 0x4B43415054505352ull || head[1] != nblocks || 32ull + 16ull * nblocks + payload > packed_len || (lw >> 63) ||
+        // (no sums of untrusted words: the host has checked packed_len >= 32 + 16 * nblocks, so the subtraction cannot wrap,
+        //  while `32 + 16 * nblocks + payload` would for a payload word near 2^64)
+        if (head[0] != 0x4B43415054505352ull || head[1] != nblocks || payload > packed_len - (32ull + 16ull * nblocks) || (lw >> 63) ||
             off > payload || len > payload - off)
             bad = true;
         const uint32_t nbi = (uint32_t)(lw >> 56) & 0xFu;

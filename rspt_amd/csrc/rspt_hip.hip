@@ -182,6 +182,8 @@ struct rspt_hip_packer {
     uint8_t* m_dst[2] = {nullptr, nullptr};   // device
     uint64_t* m_sizes[2] = {nullptr, nullptr};  // device
     uint64_t* m_hsizes = nullptr;             // page-locked host, 2 x chunk
+    uint64_t* m_idx[2] = {nullptr, nullptr};  // device: [4 + 2 x chunk] a container header + index over a slot's streams (decompress_many with src_len)
+    uint64_t* m_hidx = nullptr;               // page-locked host, 2 x (4 + 2 x chunk)
     size_t m_chunk = 0, m_stride = 0;
     hipStream_t m_up = nullptr, m_down = nullptr;
     hipEvent_t m_ev_up[2] = {}, m_ev_comp[2] = {}, m_ev_down[2] = {};
@@ -454,6 +456,29 @@ static void free_workspace(rspt_hip_packer* p) {
     p->cap_blocks = 0;
 }
 
+// everything ensure_many() creates; leaves the fields null so that a later call can start over
+static void free_many(rspt_hip_packer* p) {
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->m_src[i]);
+        hipFree(p->m_dst[i]);
+        hipFree(p->m_sizes[i]);
+        hipFree(p->m_idx[i]);
+        p->m_src[i] = p->m_dst[i] = nullptr;
+        p->m_sizes[i] = p->m_idx[i] = nullptr;
+        if (p->m_ev_up[i]) hipEventDestroy(p->m_ev_up[i]);
+        if (p->m_ev_comp[i]) hipEventDestroy(p->m_ev_comp[i]);
+        if (p->m_ev_down[i]) hipEventDestroy(p->m_ev_down[i]);
+        p->m_ev_up[i] = p->m_ev_comp[i] = p->m_ev_down[i] = nullptr;
+    }
+    if (p->m_hsizes) hipHostFree(p->m_hsizes);
+    if (p->m_hidx) hipHostFree(p->m_hidx);
+    p->m_hsizes = p->m_hidx = nullptr;
+    if (p->m_up) hipStreamDestroy(p->m_up);
+    if (p->m_down) hipStreamDestroy(p->m_down);
+    p->m_up = p->m_down = nullptr;
+    p->m_chunk = p->m_stride = 0;
+}
+
 int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps, size_t nch, size_t ns, size_t nb, int device) {
     if (!out) return RSPT_HIP_ERR_ARG;
     *out = nullptr;
@@ -696,17 +721,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
-    for (int i = 0; i < 2; ++i) {
-        hipFree(p->m_src[i]);
-        hipFree(p->m_dst[i]);
-        hipFree(p->m_sizes[i]);
-        if (p->m_ev_up[i]) hipEventDestroy(p->m_ev_up[i]);
-        if (p->m_ev_comp[i]) hipEventDestroy(p->m_ev_comp[i]);
-        if (p->m_ev_down[i]) hipEventDestroy(p->m_ev_down[i]);
-    }
-    if (p->m_hsizes) hipHostFree(p->m_hsizes);
-    if (p->m_up) hipStreamDestroy(p->m_up);
-    if (p->m_down) hipStreamDestroy(p->m_down);
+    free_many(p);
     hipFree(p->swapbuf);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
@@ -1068,10 +1083,15 @@ static int ensure_many(rspt_hip_packer* p) {
         ok &= hipEventCreateWithFlags(&p->m_ev_comp[i], hipEventDisableTiming) == hipSuccess;
         ok &= hipEventCreateWithFlags(&p->m_ev_down[i], hipEventDisableTiming) == hipSuccess;
     }
+    for (int i = 0; i < 2; ++i) ok &= hipMalloc(&p->m_idx[i], (4 + 2 * chunk) * sizeof(uint64_t)) == hipSuccess;
     ok &= hipHostMalloc((void**)&p->m_hsizes, 2 * chunk * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+    ok &= hipHostMalloc((void**)&p->m_hidx, 2 * (4 + 2 * chunk) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
     ok &= hipStreamCreateWithFlags(&p->m_up, hipStreamNonBlocking) == hipSuccess;
     ok &= hipStreamCreateWithFlags(&p->m_down, hipStreamNonBlocking) == hipSuccess;
-    if (!ok) return RSPT_HIP_ERR_ALLOC;
+    if (!ok) {  // nothing half-made stays behind: a retry starts from null fields instead of allocating over live pointers
+        free_many(p);
+        return RSPT_HIP_ERR_ALLOC;
+    }
     p->m_chunk = chunk;
     p->m_stride = stride;
     return rspt_hip_reserve(p, chunk);
@@ -1160,7 +1180,9 @@ int rspt_hip_decompress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t 
 int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t packed_len, size_t nblocks, void* d_dst, uint64_t* d_consumed,
                                    void* stream) {
     if (!d_packed || (reinterpret_cast<uintptr_t>(d_packed) & 15)) return RSPT_HIP_ERR_ARG;
-    if (packed_len < 32 + 16 * nblocks) return RSPT_HIP_ERR_CORRUPT;  // header + index must be there before the device reads them
+    // header + index must be there before the device reads them (compared without a product that could wrap for a huge nblocks)
+    if (nblocks == 0 || nblocks > 65535) return RSPT_HIP_ERR_ARG;
+    if (packed_len < 32 || nblocks > (packed_len - 32) / 16) return RSPT_HIP_ERR_CORRUPT;
     const uint8_t* base = (const uint8_t*)d_packed;
     // header 32 bytes, index 16 bytes per stream, then the payload the offsets are relative to
     return decompress_dev(p, base + 32 + 16 * nblocks, 0, reinterpret_cast<const uint64_t*>(base + 32), packed_len, nblocks, d_dst, d_consumed,
@@ -1194,17 +1216,32 @@ static int decompress_many_pipeline(rspt_hip_packer* p, const void* src_host, si
             HIPCHK(p, hipStreamWaitEvent(p->m_up, p->m_ev_comp[slot], 0));     // chunk k-2 has been decoded out of this slot
             HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_down[slot], 0));  // ... and its blocks have left it
         }
+        uint64_t* hidx = nullptr;
         if (src_len) {
+            // Only src_len[i] bytes of every stream go up, into a slot that still holds an earlier chunk's bytes behind them: the
+            // decoder is therefore bounded by each stream's OWN length -- an index over the slot in the container's form
+            // (offset, length; nb 0 = the handle's state), checked on the device like any container -- and not by the slot stride.
+            hidx = p->m_hidx + (size_t)slot * (4 + 2 * C);
+            if (k >= 2) HIPCHK(p, hipEventSynchronize(p->m_ev_up[slot]));  // (the upload of chunk k-2 has read this staging index)
+            hidx[0] = 0x4B43415054505352ull;
+            hidx[1] = cnt;
+            hidx[2] = (uint64_t)cnt * p->m_stride;
+            hidx[3] = 0;
             for (size_t i = 0; i < cnt; ++i) {
                 const size_t nbytes = src_len[first + i] < src_stride ? src_len[first + i] : src_stride;
+                hidx[4 + 2 * i] = (uint64_t)i * p->m_stride;
+                hidx[4 + 2 * i + 1] = nbytes;
                 if (nbytes) HIPCHK(p, hipMemcpyAsync(p->m_dst[slot] + i * p->m_stride, src + (first + i) * src_stride, nbytes, hipMemcpyHostToDevice, p->m_up));
             }
+            HIPCHK(p, hipMemcpyAsync(p->m_idx[slot], hidx, (4 + 2 * cnt) * sizeof(uint64_t), hipMemcpyHostToDevice, p->m_up));
         } else {
             HIPCHK(p, hipMemcpy2DAsync(p->m_dst[slot], p->m_stride, src + first * src_stride, src_stride, src_stride, cnt, hipMemcpyHostToDevice, p->m_up));
         }
         HIPCHK(p, hipEventRecord(p->m_ev_up[slot], p->m_up));
         HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_up[slot], 0));
-        const int rc = rspt_hip_decompress_batch_dev(p, p->m_dst[slot], p->m_stride, cnt, p->m_src[slot], p->m_sizes[slot], (void*)p->stream);
+        const int rc = hidx ? decompress_dev(p, p->m_dst[slot], 0, p->m_idx[slot] + 4, 32 + 16 * cnt + cnt * p->m_stride, cnt, p->m_src[slot],
+                                             p->m_sizes[slot], (void*)p->stream)
+                            : rspt_hip_decompress_batch_dev(p, p->m_dst[slot], p->m_stride, cnt, p->m_src[slot], p->m_sizes[slot], (void*)p->stream);
         if (rc) return rc;
         HIPCHK(p, hipMemcpyAsync(p->m_hsizes + (size_t)slot * C, p->m_sizes[slot], cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
         HIPCHK(p, hipEventRecord(p->m_ev_comp[slot], p->stream));

@@ -244,6 +244,18 @@ def test_decompress_packed_rejects_a_damaged_container(api, orc):
     u = used.cpu().numpy().view(np.uint64)
     assert [int(x >> 63) for x in u] == [0, 0, 1, 0]
     assert torch.equal(out[0], d_src[0]) and torch.equal(out[3], d_src[3])
+    # (c) a payload word near 2^64: `32 + 16 n + payload` would wrap to a small number and pass a naive bound check
+    bad = good.clone()
+    bad[16:24].view(torch.int64)[0] = -16  # payload bytes = 2^64 - 16
+    bad[32 : 32 + 16 * B].view(torch.int64)[2 * 1] = 1 << 40  # ... and then any offset would be "inside the payload"
+    _, used = pk.decompress_packed(bad)
+    torch.cuda.synchronize()
+    assert all(int(x) >> 63 for x in used.cpu().numpy().view(np.uint64))
+    # (d) a block count that does not fit the container (16 * nblocks wraps in 64 bits): refused on the host, before anything is sized from it
+    bad = good.clone()
+    bad[8:16].view(torch.int64)[0] = 1 << 60
+    with pytest.raises(api.RsptHipError):
+        pk.decompress_packed(bad)
     pk.close()
 
 
