@@ -319,7 +319,9 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
                                                          const uint32_t* __restrict__ nbuse, const uint32_t* __restrict__ nzflag,
                                                          uint32_t nhb_total, uint32_t* __restrict__ cw, uint32_t* __restrict__ tdesc,
                                                          BlockMeta* __restrict__ meta, const uint32_t* __restrict__ seghist,
-                                                         uint32_t* __restrict__ segbase, uint32_t* __restrict__ zero_next, uint32_t zero_words) {
+                                                         uint32_t* __restrict__ segbase, uint32_t* __restrict__ zero_next, uint32_t zero_words,
+                                                         uint32_t psel_arg) {
+    const uint32_t psel = RSPT_DIAG_ONLY(psel_arg);  // timing probes (diagnostic builds only): no tree for plane 0 (bit 4) / planes >= 1 (bit 5)
     __shared__ TreeLds s_t[kTreeWaves];
     const uint32_t l = lane_id();
     const uint32_t wv = threadIdx.x >> 6;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         if (l == 0) meta[hb] = BlockMeta{kModeSkip, 0, 0, 0};
         return;
     }
-    const uint32_t segmask = nzflag[hb];
+    const uint32_t segmask = (psel && ((k == 0 && (psel & 16u)) || (k >= 1 && (psel & 32u)))) ? 0u : nzflag[hb];
     if (!segmask) {  // all-zero block (flagged by the front end): EncodeFill with value 0
         if (l == 0) meta[hb] = BlockMeta{kModeFill, 1u, 0u, 0u};
         return;
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
                                                uint64_t* __restrict__ out_off, uint64_t* __restrict__ sizes, const CrcConsts* __restrict__ cc,
                                                const uint32_t* __restrict__ nzflag, WorkQueues* __restrict__ wq,
                                                uint32_t* __restrict__ big_list, uint32_t* __restrict__ small_list,
-                                               uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift) {
+                                               uint32_t* __restrict__ plane_dirty, uint32_t dirty_shift, uint32_t psel_arg) {
+    const uint32_t psel = RSPT_DIAG_ONLY(psel_arg);  // timing probes (diagnostic builds only): k_encode gets no plane 0 (bit 2) / planes >= 1 (bit 3)
     __shared__ uint64_t s_part[256];
     __shared__ uint64_t s_plane_end[kMaxPlanes + 1];
     __shared__ uint32_t s_dirty[kMaxPlanes * 4];  // 128 bits per plane: hzr blocks (j >> dirty_shift) that keep their data
@@ -491,6 +494,7 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
                    __popc(nzflag[hb0 + q]) <= (int)kSmallSegments) {
             small_list[atomicAdd(&wq->n_small, 1u)] = hb0 + q;
         } else if (m.mode == kModeHuff || m.mode == kModeCopy) {
+            if (psel && ((q / g.nblk == 0 && (psel & 4u)) || (q / g.nblk >= 1 && (psel & 8u)))) continue;
             big_list[atomicAdd(&wq->n_big, 1u)] = hb0 + q;
         }
     }

@@ -674,7 +674,8 @@ __shared__ HistLds g_h;
 
 // The blocks k_hist takes (a plane in use, more than kSmallSegments non-zero segments), in any order: work_ctr[2] = count.
 __global__ __launch_bounds__(256) void k_histlist(const uint32_t* __restrict__ nzflag, const uint32_t* __restrict__ nbuse, Geom g, uint32_t nhb_total,
-                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+                                                 uint32_t* __restrict__ list, uint32_t* __restrict__ count, uint32_t psel_arg) {
+    const uint32_t psel = RSPT_DIAG_ONLY(psel_arg);  // timing probes (diagnostic builds only): leave out plane 0 (bit 0) / planes >= 1 (bit 1)
     const uint32_t v = blockIdx.x * 256u + threadIdx.x, l = lane_id();
     bool take = false;
     uint32_t hb = 0;
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(256) void k_histlist(const uint32_t* __restrict__ n
         const uint32_t k = v % kMaxPlanes, j = (v / kMaxPlanes) % g.nblk, b = v / (kMaxPlanes * g.nblk);
         hb = hb_index(g, b, k, j);
         take = k < nbuse[b] && (uint32_t)__popc(nzflag[hb]) > kSmallSegments;
+        if (psel && ((k == 0 && (psel & 1u)) || (k >= 1 && (psel & 2u)))) take = false;
     }
     const unsigned long long m = __ballot(take);
     if (!m) return;
@@ -733,7 +735,11 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
             const uint32_t wv = tid >> 6;
             ListSink sink{lists + ((size_t)hb * kEncWaves + wv) * kListCap, 0u};
             const uint32_t before = rc[0].rb - rc[0].zb0;  // position behind the last literal in front of this wave's segment
+#ifdef RSPT_PROBE_NOROWS  // timing probe (never in the product): everything but the row bodies
+            asm volatile("" ::"v"(W[0][0] ^ W[1][1] ^ W[2][2] ^ W[3][3]), "s"(rc[0].zb0 + rc[1].zb0 + rc[2].zb0 + rc[3].zb0));
+#else
             hist_rows(W, rc, in_size, d.hist[wv], d.runcls, d.queue[wv], sink);
+#endif
             if ((tid & 63u) == 0) listinfo[(size_t)hb * kEncWaves + wv] = make_uint2(sink.n, before);
         }
         uint32_t in_size_n = 0;
@@ -743,6 +749,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
             issue_block_loads(in_n, in_size_n, segn, W);
         }
         __syncthreads();
+#ifndef RSPT_PROBE_NOREDUCE  // timing probe (never in the product): no block / segment histograms leave the workgroup
         if (tid < (uint32_t)kSymStride) {
             uint32_t t = 0;
 #pragma unroll
@@ -756,6 +763,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_hist(const uint8_t* __restri
         }
         __syncthreads();  // everyone has read the histograms
         for (uint32_t i = tid; i < (uint32_t)kEncWaves * kSymStride; i += kEncThreads) (&d.hist[0][0])[i] = 0;
+#endif
         cur = nxt;
         hb = hbn;
         in_size = in_size_n;

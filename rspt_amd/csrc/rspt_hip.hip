@@ -196,6 +196,7 @@ struct rspt_hip_packer {
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
     uint32_t ablate = 0;  // RSPT_ABLATE (diagnostic builds only; the product kernels ignore it): timing probes
+    uint32_t psel = 0;    // RSPT_PLANESEL (diagnostic builds only): which planes the hzr kernels take; bit 8 / 9: stop behind k_hist / k_tree
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
     int big_endian = 0;   // samples arrive / leave with their bytes reversed (rspt_hip_set_byte_order)
     uint8_t* swapbuf = nullptr;  // [cap * block_bytes] byte-swapped copy of the input
@@ -552,6 +553,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
     }
 #ifdef RSPT_DIAG  // timing probes and tuning knobs: never in the product library
     if (const char* e = getenv("RSPT_ABLATE")) p->ablate = (uint32_t)atoi(e);
+    if (const char* e = getenv("RSPT_PLANESEL")) p->psel = (uint32_t)atoi(e);
     if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
     if (const char* e = getenv("RSPT_K1_GRID")) p->k1_grid = (uint32_t)atoi(e);
 #endif
@@ -852,7 +854,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         if (!p->zero_ready[p->zset]) HIPCHK(p, hipMemsetAsync(p->nzflag, 0, zwords * sizeof(uint32_t), st));  // (first call, or after a failed one)
         p->zero_ready[0] = p->zero_ready[1] = false;  // this copy is in use now; the other one becomes ready once k_tree is launched
     }
-    if (p->planes_unknown || p->ablate) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave)
+    if (p->planes_unknown || p->ablate || p->psel) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave)
         HIPCHK(p, hipMemsetAsync(p->plane_dirty, 0xFF, p->cap_blocks * kMaxPlanes * 4 * sizeof(uint32_t), st));
         p->planes_unknown = false;
     }
@@ -905,21 +907,33 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const uint32_t nhb = B * kMaxPlanes * g.nblk;
     const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
     // (the list of k_hist's blocks sits in big_list until k_layout refills that array for k_encode; its count in work_ctr[2])
-    hipLaunchKernelGGL(k_histlist, dim3((nhb + 255) / 256), dim3(256), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, p->work_ctr + 2);
+    hipLaunchKernelGGL(k_histlist, dim3((nhb + 255) / 256), dim3(256), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, p->work_ctr + 2, p->psel);
     hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->hist, p->seghist, p->work_ctr, p->big_list,
                        p->work_ctr + 2, p->lists, p->listinfo);
     HIPCHK(p, hipGetLastError());  // (a failing launch is reported at its own stage)
 
     stamp(p, ST_TREE, st);
+    if (p->psel & 256u) {  // (diagnostic builds only: time the front end and k_hist alone)
+        for (int i = ST_TREE + 1; i <= ST_COUNT; ++i) stamp(p, i, st);
+        if (p->profiling) p->ev_valid = true;
+        return RSPT_HIP_OK;
+    }
     hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase,
-                       p->zbuf[p->zset ^ 1], (uint32_t)p->zcap_words);
+                       p->zbuf[p->zset ^ 1], (uint32_t)p->zcap_words, p->psel);
     HIPCHK(p, hipGetLastError());
     const int zset_next = p->zset ^ 1;
 
     stamp(p, ST_LAYOUT, st);
+    if (p->psel & 512u) {  // (diagnostic builds only: stop behind k_tree)
+        for (int i = ST_LAYOUT + 1; i <= ST_COUNT; ++i) stamp(p, i, st);
+        if (p->profiling) p->ev_valid = true;
+        p->zero_ready[zset_next] = true;
+        p->zset = zset_next;
+        return RSPT_HIP_OK;
+    }
     WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
     hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
-                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift);
+                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift, p->psel);
     HIPCHK(p, hipGetLastError());
 
     stamp(p, ST_ENCODE, st);

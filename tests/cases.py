@@ -200,7 +200,11 @@ def dct_big_cases():
     """dct beyond the dense-table limit of the GPU build (ns > 8192) where the REAL reference can still run (n x n float
     table: 1 GiB at 16384; ~20 s per case here).  The reference's full stream is the fixture: the FFT path is held to it."""
     return [dict(name="synth2x16384_dct", kind="dct", bps=4, nch=2, ns=16384, nb=2,
-                 data=np.ascontiguousarray(synth.synth_native(2, 16384, block_index=11, ecg=True).numpy().reshape(-1)))]
+                 data=np.ascontiguousarray(synth.synth_native(2, 16384, block_index=11, ecg=True).numpy().reshape(-1))),
+            # the reference's own limit: at ns = 32768 its table index (2x+1)*i still fits an int (signal_packer_dct.cpp:60-74) and
+            # the table is 4 GiB -- one octave below BASELINE config 4 (ns = 65536), where only the restatement can check
+            dict(name="synth1x32768_dct", kind="dct", bps=4, nch=1, ns=32768, nb=2,
+                 data=np.ascontiguousarray(synth.synth_native(1, 32768, block_index=13, ecg=True).numpy().reshape(-1)))]
 
 
 def dct_dense_big_cases():
