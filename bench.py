@@ -267,6 +267,9 @@ def main():
         recv_bufs = [None] + [torch.empty(pk.pack_bound(shard.shard_range(args.blocks, r, world)[1] if c5 else B), dtype=torch.uint8, device=dev)
                               for r in range(1, world)]
     gathered_bytes = [0]
+    # c5: the containers of step i leave during step i + 1 (sizes by a device all-gather, read by the host one step later: no host
+    # round trip inside a step; rspt_amd/shard.py LaggedGather); the last step's payload is flushed inside the timed region
+    lag = shard.LaggedGather(dst=0, recv_bufs=recv_bufs, device=dev) if (do_gather and c5) else None
     slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
     sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if (do_gather and not c5) else None
 
@@ -287,11 +290,11 @@ def main():
         if c5:
             # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step
             pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
+            if lag is not None:
+                lag.wait_slot_free(slot)  # (the container of two steps ago has left this buffer)
             pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
-            if do_gather:
-                got = shard.gather_containers(packed[slot], totals[slot], dst=0, recv_bufs=recv_bufs)
-                if got is not None:
-                    gathered_bytes[0] = sum(n for _, n in got)
+            if lag is not None:
+                lag.step(packed[slot], totals[slot])
             return
         if slot_free[slot] is not None and not slot_free[slot].query():  # (two steps old: almost always done -- then no barrier packet)
             stream.wait_event(slot_free[slot])
@@ -315,6 +318,8 @@ def main():
                 slot_free[slot].record(side)
 
     def fence():
+        if lag is not None:
+            lag.flush()  # the last step's containers travel inside the timed region
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -333,6 +338,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if lag is not None:
+        gathered_bytes[0] = lag.gathered_bytes
     # c3, N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
     # could take the output of only 2-3 GPUs at this rate); its time is reported beside the metric
     gather_ms = None
@@ -463,9 +470,11 @@ def main():
                              "device-resident" % (args.packer, args.nb, B, shape)),
                 "blocks_per_gpu": B,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
-                "gather": ("every step, inside the timed region" if payload_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
+                "gather": ("every step, inside the timed region%s" % (" (sizes by device all-gather, payload one step behind: no host sync in the step)" if lag is not None else "")
+                           if payload_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
                 "gathered_bytes": gathered_bytes[0],
                 "gather_ms": round(gather_ms, 3) if gather_ms is not None else None,
+                "gather_ms_per_step": (lambda v: round(v, 4) if v is not None else None)(lag.mean_payload_ms()) if lag is not None else None,
                 "parallelism": "shard%d" % world,
             },
             "roofline": {

@@ -194,6 +194,33 @@ int rspt_hip_pack_batch_dev(rspt_hip_packer* p, const void* d_dst, size_t dst_st
 int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, size_t packed_len, size_t nblocks, void* d_dst, uint64_t* d_consumed,
                                    void* stream);
 
+/* ---- multi-GPU: gather the containers of all ranks to one rank over RCCL -----------------------------
+ * One process (or thread) per GPU, each with its own handle and its own ncclComm_t of one communicator.  The ranks hold
+ * contiguous shards of independent blocks (no data-path collective); what travels is the result: the sizes by
+ * ncclAllGather, the payload as ONE group of ncclSend / ncclRecv straight from every peer to the root (a gatherv over the
+ * direct xGMI links; no ring).  `comm` is the caller's ncclComm_t, passed as void* so that this header needs no RCCL
+ * header; the library binds to the RCCL the process has loaded (librccl.so.1) at the first call and fails with
+ * RSPT_HIP_ERR_UNSUPPORTED when there is none.
+ *
+ *   rspt_hip_gather_sizes     d_total (device u64: this rank's container length, as rspt_hip_pack_batch_dev wrote it) ->
+ *                             d_totals[world] on every rank, and -- if h_totals is not NULL -- a copy in the caller's
+ *                             page-locked host array h_totals[world] (asynchronous: valid once `stream` has got there)
+ *   rspt_hip_gather_payload   with the sizes known on the host: root receives rank r's container at
+ *                             d_recv + r * recv_stride (its own is copied there too), the others send theirs.
+ *                             recv_stride >= the largest container (rspt_hip_pack_bound() always suffices), the SAME value
+ *                             on every rank: a container that does not fit makes every rank return
+ *                             RSPT_HIP_ERR_DST_TOO_SMALL before anything is posted
+ *   rspt_hip_gather_containers  both, with one stream synchronisation in between (the sizes must reach the host before
+ *                             the transfers can be posted); h_totals[world] receives the sizes on every rank.
+ *                             A caller that gathers every step posts the payload of step i after the sizes of step
+ *                             i+1 instead (no synchronisation: see rspt_amd/shard.py LaggedGather for the pattern).
+ * All ranks must make the same calls in the same order.  Asynchronous on `stream` except where said. */
+int rspt_hip_gather_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, uint64_t* d_totals, uint64_t* h_totals, void* stream);
+int rspt_hip_gather_payload(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* h_totals,
+                            void* d_recv, size_t recv_stride, void* stream);
+int rspt_hip_gather_containers(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* d_total,
+                               void* d_recv, size_t recv_stride, uint64_t* h_totals, void* stream);
+
 /* ---- optional stage in front of compress: the reference's IIR pre-filter ---------------------------------------
  * Replaces the filter step of the reference's own pipeline (lib_rspt_test/rspt_test.cpp:116-136): i_filter::new_iir
  * (n, d, nr_coefficients), init_history_values(first sample of the channel, init_nr_samples), filter_opt on every sample

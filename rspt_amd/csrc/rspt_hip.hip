@@ -8,6 +8,7 @@
 #include "../../include/rspt_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -184,6 +185,8 @@ struct rspt_hip_packer {
     uint64_t* m_hsizes = nullptr;             // page-locked host, 2 x chunk
     uint64_t* m_idx[2] = {nullptr, nullptr};  // device: [4 + 2 x chunk] a container header + index over a slot's streams (decompress_many with src_len)
     uint64_t* m_hidx = nullptr;               // page-locked host, 2 x (4 + 2 x chunk)
+    uint64_t* gat_totals = nullptr;           // device [gat_world]: container lengths of all ranks (rspt_hip_gather_containers)
+    int gat_world = 0;
     size_t m_chunk = 0, m_stride = 0;
     hipStream_t m_up = nullptr, m_down = nullptr;
     hipEvent_t m_ev_up[2] = {}, m_ev_comp[2] = {}, m_ev_down[2] = {};
@@ -724,6 +727,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_dst);
     hipFree(p->h_size);
     free_many(p);
+    hipFree(p->gat_totals);
     hipFree(p->swapbuf);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
@@ -1441,6 +1445,90 @@ int rspt_hip_iir_prefilter_batch_dev(rspt_hip_packer* p, void* d_buf, size_t nbl
     }
     HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
+}
+
+// ---- multi-GPU gather over RCCL.  RCCL is bound at run time: a process that never gathers (the C++ drop-in on one
+// GPU, the tests on the CPU box) does not load it, and a process that does gather uses the very library its ncclComm_t came from.
+namespace {
+struct Rccl {
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+constexpr int kNcclUint8 = 1, kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
+const Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl q;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return q;
+        q.AllGather = reinterpret_cast<decltype(q.AllGather)>(dlsym(h, "ncclAllGather"));
+        q.Send = reinterpret_cast<decltype(q.Send)>(dlsym(h, "ncclSend"));
+        q.Recv = reinterpret_cast<decltype(q.Recv)>(dlsym(h, "ncclRecv"));
+        q.GroupStart = reinterpret_cast<decltype(q.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        q.GroupEnd = reinterpret_cast<decltype(q.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        q.ok = q.AllGather && q.Send && q.Recv && q.GroupStart && q.GroupEnd;
+        return q;
+    }();
+    return r;
+}
+}  // namespace
+
+int rspt_hip_gather_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, uint64_t* d_totals, uint64_t* h_totals, void* stream) {
+    if (!p || !comm || world < 1 || !d_total || !d_totals) return RSPT_HIP_ERR_ARG;
+    const Rccl& R = rccl();
+    if (!R.ok) return RSPT_HIP_ERR_UNSUPPORTED;
+    HIPCHK(p, hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (R.AllGather(d_total, d_totals, 1, kNcclUint64, comm, st) != 0) return RSPT_HIP_ERR_LAUNCH;
+    if (h_totals) HIPCHK(p, hipMemcpyAsync(h_totals, d_totals, (size_t)world * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_gather_payload(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* h_totals,
+                            void* d_recv, size_t recv_stride, void* stream) {
+    if (!p || !comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || !d_packed || !h_totals) return RSPT_HIP_ERR_ARG;
+    if (rank == root && !d_recv) return RSPT_HIP_ERR_ARG;
+    const Rccl& R = rccl();
+    if (!R.ok) return RSPT_HIP_ERR_UNSUPPORTED;
+    HIPCHK(p, hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    for (int r = 0; r < world; ++r)
+        if (h_totals[r] > recv_stride) return RSPT_HIP_ERR_DST_TOO_SMALL;  // (every rank sees the same sizes and the same stride: nobody posts anything)
+    // one group: the root's receives and the peers' sends are matched pairwise, straight over each peer's own link to the root
+    if (R.GroupStart() != 0) return RSPT_HIP_ERR_LAUNCH;
+    int rc = 0;
+    if (rank == root) {
+        for (int r = 0; r < world && !rc; ++r)
+            if (r != root && h_totals[r]) rc = R.Recv((uint8_t*)d_recv + (size_t)r * recv_stride, (size_t)h_totals[r], kNcclUint8, r, comm, st);
+    } else if (h_totals[rank]) {
+        rc = R.Send(d_packed, (size_t)h_totals[rank], kNcclUint8, root, comm, st);
+    }
+    if (R.GroupEnd() != 0 || rc) return RSPT_HIP_ERR_LAUNCH;
+    if (rank == root && h_totals[root])
+        HIPCHK(p, hipMemcpyAsync((uint8_t*)d_recv + (size_t)root * recv_stride, d_packed, (size_t)h_totals[root], hipMemcpyDeviceToDevice, st));
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_gather_containers(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* d_total,
+                               void* d_recv, size_t recv_stride, uint64_t* h_totals, void* stream) {
+    if (!p || !h_totals || world < 1) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    if (p->gat_world < world) {  // (a few words, kept with the handle)
+        hipFree(p->gat_totals);
+        p->gat_totals = nullptr;
+        p->gat_world = 0;
+        if (hipMalloc(&p->gat_totals, (size_t)world * sizeof(uint64_t)) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+        p->gat_world = world;
+    }
+    uint64_t* d_all = p->gat_totals;
+    int rc = rspt_hip_gather_sizes(p, comm, world, d_total, d_all, h_totals, stream);
+    if (rc == RSPT_HIP_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = RSPT_HIP_ERR_LAUNCH;  // the sizes are on the host now
+    if (rc == RSPT_HIP_OK) rc = rspt_hip_gather_payload(p, comm, rank, world, root, d_packed, h_totals, d_recv, recv_stride, stream);
+    return rc;
 }
 
 long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, size_t cap) {

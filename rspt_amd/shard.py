@@ -94,3 +94,122 @@ def gather_containers(packed, total, dst=0, group=None, recv_bufs=None):
     for q in reqs:
         q.wait()
     return out
+
+
+class LaggedGather:
+    """The gather of one container per rank and step, WITHOUT a host round trip inside the step.
+
+    A gatherv needs the byte counts on the host of both ends before the payload transfers can be posted.  Reading them in
+    the step they are produced in (gather_containers: `.item()`) stalls the host once per step behind the step's kernels.
+    Here the sizes of step i travel by an all-gather on the device (ncclAllGather of the sizes) and a copy into
+    page-locked host memory, both on a side stream; the host looks at them one step later -- when they have long arrived --
+    and posts the payload of step i then, as one group of send / recv (ncclGroupStart ... ncclGroupEnd), again on the side
+    stream.  flush() posts the last step's payload.  The payload of a step therefore overlaps the kernels of the next one.
+
+        lag = LaggedGather(dst=0, recv_bufs=..., device=dev)        # recv_bufs[r]: bound-sized buffer per source rank (dst only)
+        for i in steps:
+            ...kernels that write packed[i & 1], totals[i & 1] on the current stream...
+            done = lag.step(packed[i & 1], totals[i & 1])           # -> what arrived for step i-1 (dst) / None
+            # before packed[i & 1] is written again (two steps on): lag.wait_slot_free(i & 1)
+        last = lag.flush()
+
+    Works over gloo with CPU tensors too (no streams: everything is immediate), which is how the CPU tests run it.
+    """
+
+    def __init__(self, dst=0, group=None, recv_bufs=None, device=None):
+        import torch
+        import torch.distributed as dist
+
+        self.dist, self.torch = dist, torch
+        self.group, self.dst = group, dst
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.recv_bufs = recv_bufs
+        self.cuda = device is not None and torch.device(device).type == "cuda"
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        self.sizes_dev = [torch.zeros(self.world, dtype=torch.int64, device=self.device) for _ in range(2)]
+        self.sizes_host = [torch.zeros(self.world, dtype=torch.int64).pin_memory() if self.cuda else torch.zeros(self.world, dtype=torch.int64)
+                           for _ in range(2)]
+        self.ev_sizes = [None, None]
+        self.slot_free = [None, None]
+        self.pending = None  # (slot, packed tensor) whose payload has not been posted yet
+        self.k = 0
+        self.payload_ms = []  # (start, end) event pairs of the payload groups (dst)
+        self.gathered_bytes = 0
+
+    def _post_payload(self, slot, packed):
+        """sizes of `slot` are on the host by now (their event is a step old): post the group of transfers"""
+        dist, torch = self.dist, self.torch
+        if self.ev_sizes[slot] is not None:
+            self.ev_sizes[slot].synchronize()  # (recorded a whole step ago: does not wait in the steady state)
+        sizes = [int(x) for x in self.sizes_host[slot].tolist()]
+        ops, out = [], None
+        if self.rank != self.dst:
+            ops.append(dist.P2POp(dist.isend, packed[: sizes[self.rank]], self.dst, self.group))
+        else:
+            out = []
+            for r in range(self.world):
+                if r == self.dst:
+                    out.append((packed, sizes[r]))
+                    continue
+                buf = self.recv_bufs[r] if self.recv_bufs is not None else torch.empty(sizes[r], dtype=torch.uint8, device=packed.device)
+                ops.append(dist.P2POp(dist.irecv, buf[: sizes[r]], r, self.group))
+                out.append((buf, sizes[r]))
+            self.gathered_bytes = sum(n for _, n in out)
+        if self.cuda:
+            with torch.cuda.stream(self.side):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(self.side)
+                reqs = dist.batch_isend_irecv(ops) if ops else []
+                for q in reqs:
+                    q.wait()  # (stream-ordered for nccl: no host wait)
+                e1.record(self.side)
+                self.payload_ms.append((e0, e1))
+                self.slot_free[slot] = e1
+        else:
+            for q in (dist.batch_isend_irecv(ops) if ops else []):
+                q.wait()
+        return out
+
+    def step(self, packed, total):
+        """Call behind the kernels that produced `packed` / `total` (enqueued on the current stream)."""
+        dist, torch = self.dist, self.torch
+        slot = self.k & 1
+        done = None
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                dist.all_gather_into_tensor(self.sizes_dev[slot], total.view(1), group=self.group)
+                self.sizes_host[slot].copy_(self.sizes_dev[slot], non_blocking=True)
+                self.ev_sizes[slot] = torch.cuda.Event()
+                self.ev_sizes[slot].record(self.side)
+        else:
+            parts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(parts, total.view(1), group=self.group)
+            self.sizes_host[slot].copy_(torch.cat(parts))
+        if self.pending is not None:
+            done = self._post_payload(*self.pending)
+        self.pending = (slot, packed)
+        self.k += 1
+        return done
+
+    def flush(self):
+        done = None
+        if self.pending is not None:
+            done = self._post_payload(*self.pending)
+            self.pending = None
+        return done
+
+    def wait_slot_free(self, slot):
+        """make the current stream wait until the payload that last used this slot's container has left"""
+        if self.cuda and self.slot_free[slot] is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(self.slot_free[slot])
+
+    def mean_payload_ms(self):
+        if not (self.cuda and self.payload_ms):
+            return None
+        self.torch.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in self.payload_ms) / len(self.payload_ms)

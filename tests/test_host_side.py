@@ -197,3 +197,60 @@ def test_cxx_factories_follow_the_device_setting(api, tmp_path):
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stdout
     assert "ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["c5", "c3"])
+def test_bench_under_the_launcher_with_one_rank(api, workload):
+    """The N > 1 branch of bench.py -- RANK set, init_process_group("nccl"), the side-stream exchange of sizes, the container
+    pack + (lagged) gather of --workload c5 -- through RCCL with a world of one rank: the code the driver's 2/4/8-GPU runs take,
+    on the one GPU a test box has.  Started as a child process (never an exec from this GPU-initialised process)."""
+    import json
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu"]
+    if workload == "c3":
+        cmd += ["--blocks", "4"]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 1 and r["verified"] is True and r["value"] > 0
+    assert r["scaling"] == ("strong" if workload == "c5" else "weak")
+    assert r["config"]["gather"]  # the exchange ran (a string describing it), not the --no-gather shortcut
+    if workload == "c5":
+        assert "no host sync" in r["config"]["gather"] and r["config"]["gathered_bytes"] > 0
+
+
+def _build_gather_example(tmp_path):
+    from rspt_amd import build
+
+    exe = tmp_path / "gather_devices"
+    lib_dir = os.path.dirname(build.LIB)
+    subprocess.check_call(["g++", "-std=c++11", "-pthread", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cxx", "gather_devices.cpp"), "-o", str(exe), "-L" + lib_dir, "-lrspt_hip", "-L/opt/rocm/lib",
+                           "-lrccl", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cxx_gather_example_compiles(tmp_path):
+    """tests/cxx/gather_devices.cpp: shards -> containers -> RCCL gather to rank 0 -> decode, through include/rspt_hip.h alone"""
+    assert _build_gather_example(tmp_path).exists()
+
+
+@pytest.mark.gpu
+def test_cxx_gather_over_rccl(api, tmp_path):
+    """the C ABI's gather (ncclAllGather of the sizes, grouped ncclSend / ncclRecv of the payload) with one rank per
+    visible device, each rank's container decoded on rank 0"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([str(_build_gather_example(tmp_path))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok" in out.stdout

@@ -112,3 +112,52 @@ def test_gather_world2_gloo():
             assert dec.decompress(s_)[0] == b.tobytes()
         pos += count
     assert pos == NBLOCKS
+
+
+def _lag_worker(rank, world, port, q):
+    """three steps of the lagged gather (bench.py --workload c5 does the same over RCCL): the payload of step i is
+    posted at step i + 1, the last one by flush(); every step's containers differ in size and content"""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lag = shard.LaggedGather(dst=0)
+    got = []
+    for i in range(3):
+        streams = [bytes([rank * 16 + i]) * (5 + 7 * i + 3 * rank + j) for j in range(2 + rank)]
+        cont = shard.pack_container(streams, 2)
+        packed = torch.frombuffer(bytearray(cont) + bytearray(64), dtype=torch.uint8)  # (a buffer longer than the container)
+        done = lag.step(packed, torch.tensor([len(cont)], dtype=torch.int64))
+        assert (done is None) == (i == 0 or rank != 0)
+        if done is not None:
+            got.append([bytes(t[:n].numpy().tobytes()) for t, n in done])
+    done = lag.flush()
+    if rank == 0:
+        got.append([bytes(t[:n].numpy().tobytes()) for t, n in done])
+        q.put(got)
+    assert lag.flush() is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_lagged_gather_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_lag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len(got) == 3
+    for i, per_rank in enumerate(got):
+        assert len(per_rank) == 2
+        for r, c in enumerate(per_rank):
+            streams, nb = shard.unpack_container(c)
+            assert nb == 2 and streams == [bytes([r * 16 + i]) * (5 + 7 * i + 3 * r + j) for j in range(2 + r)]
