@@ -51,6 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
     ap.add_argument("--op", default="compress", choices=["compress", "decompress"],
                     help="decompress: the timed step decodes the streams of one batch (secondary line, c3 workload, one GPU)")
+    ap.add_argument("--big-endian", action="store_true", help="feed the samples most significant byte first (rspt_hip_set_byte_order)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="c3, N>1: ship every step's streams to rank 0 (link-bound beyond 2-3 GPUs: see DESIGN.md)")
@@ -247,6 +248,12 @@ def main():
     # synthetic input, resident in HBM: TWO distinct batches alternate in the timed loop (the front end's behaviour depends on
     # what the previous call left in the plane workspace); every rank gets different blocks (SURVEY 8d generator)
     d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(2)]
+    if args.big_endian:  # the same samples, bytes reversed; the streams are the little-endian ones (checked below against the oracle)
+        d_le = d_src
+        d_src = [x.view(B, -1, args.bps).flip(2).contiguous().view(B, -1) for x in d_le]
+        pk.set_byte_order(True)
+    else:
+        d_le = d_src
     dst_stride = (pk.max_compressed_size + 255) // 256 * 256
     d_dst = [torch.empty((B, dst_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
     d_sizes = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -361,7 +368,7 @@ def main():
     if decomp:  # the last decoded batch is the input again (lossless packers), and the decoder consumed every stream in full
         last = (args.steps - 1) & 1
         ok_len = bool(torch.equal(d_used, d_sizes[last]))
-        decode_ok = ok_len and (bool(torch.equal(d_back, d_src[last])) if args.packer in ("xdelta_hzr", "hzr") else True)
+        decode_ok = ok_len and (bool(torch.equal(d_back.view(-1), d_src[last].view(-1))) if args.packer in ("xdelta_hzr", "hzr") else True)
     for s in range(2):
         pk.compress_batch(d_src[s], d_dst[s], d_sizes[s], dst_stride)
     torch.cuda.synchronize()
@@ -374,7 +381,7 @@ def main():
         verified = True
         for s in range(2):
             for b in sorted({0, B - 1}):
-                x = d_src[s][b].cpu().numpy()
+                x = d_le[s][b].cpu().numpy()
                 want = orc.dct_big_compress(x, args.bps, nch, ns)[0] if big_dct else po.compress(x)
                 n = int(d_sizes[s][b])
                 got_b = d_dst[s][b, :n].cpu().numpy().tobytes() if 0 < n <= dst_stride else b""
@@ -460,7 +467,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if c5 else "weak",
             "vs_baseline": None,
-            "dtype": "int%d" % (8 * args.bps),
+            "dtype": "int%d%s" % (8 * args.bps, " big-endian" if args.big_endian else ""),
             "data": "synthetic (parabolic sine + 4-bit counter-hash noise per SURVEY 8d; hashes differ from the survey's xorshift variant)",
             "verified": verified,
             "config": {

@@ -43,6 +43,7 @@ struct Geom {
     uint32_t hdr_len;       // 0, or 3*nch for dct/hadamard (means header)
     uint32_t method;        // stream method byte (signal_packer_base.cpp:83)
     uint32_t kind;          // rspt_hip_kind
+    uint32_t be;            // samples arrive with their bytes reversed (rspt_hip_set_byte_order): the front ends swap on the way in
     uint64_t plane_stride;  // bytes between planes in the workspace (N rounded up to 256)
     uint64_t block_bytes;   // bps*nch*ns
 };

@@ -23,8 +23,26 @@ namespace rspt {
 __device__ __forceinline__ uint32_t magic_of(uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); }
 __device__ __forceinline__ uint32_t fast_div(uint32_t q, uint32_t d, uint32_t M) { return d == 1 ? q : __umulhi(q, M); }
 
+// `be`: the sample's bytes are stored most significant first (convert_native_to_i32 with reverse_byte_order = true,
+// lib_signalpacker/utils.cpp:127-137,145-154,162-170)
 template <int BPS>
-__device__ __forceinline__ int32_t sample_from_bytes(const uint8_t* p, bool aligned) {
+__device__ __forceinline__ int32_t sample_from_bytes(const uint8_t* p, bool aligned, bool be = false) {
+    if (be) {
+        if (BPS == 4) {
+            if (aligned) {
+                const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+                return (int32_t)__builtin_amdgcn_perm(u, u, 0x00010203u);
+            }
+            return (int32_t)((uint32_t)p[3] | ((uint32_t)p[2] << 8) | ((uint32_t)p[1] << 16) | ((uint32_t)p[0] << 24));
+        } else if (BPS == 3) {
+            const uint32_t u = (uint32_t)p[2] | ((uint32_t)p[1] << 8) | ((uint32_t)p[0] << 16);
+            return (int32_t)(u << 8) >> 8;
+        } else if (BPS == 2) {
+            const uint32_t u = (uint32_t)p[1] | ((uint32_t)p[0] << 8);
+            return (int32_t)(u << 16) >> 16;
+        }
+        return (int32_t)(int8_t)p[0];
+    }
     if (BPS == 4) {
         if (aligned) return *reinterpret_cast<const int32_t*>(p);
         uint32_t u = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -46,7 +64,7 @@ __device__ __forceinline__ int32_t sample_global(const uint8_t* blk, const Geom&
     if (flat < 0) return 0;
     uint32_t f = (uint32_t)flat;
     uint32_t c = f / g.ns, s = f - c * g.ns;
-    return sample_from_bytes<BPS>(blk + ((size_t)s * g.nch + c) * BPS, false);
+    return sample_from_bytes<BPS>(blk + ((size_t)s * g.nch + c) * BPS, false, g.be != 0);
 }
 
 __device__ __forceinline__ uint32_t need_from_mask(uint32_t m) { return m < 0x80u ? 1u : m < 0x8000u ? 2u : m < 0x800000u ? 3u : 4u; }
@@ -97,18 +115,19 @@ __device__ __forceinline__ void load_item(const uint8_t* blk, const Geom& g, uin
     const uint32_t t0 = grp << 4;
     const uint32_t cnt = min(16u, Tn - t0);
     const uint8_t* col = blk + ((size_t)(s0 + t0) * g.nch + c) * BPS;  // sample (s0+t0, c); next sample: + nch*BPS
+    const bool be = g.be != 0;
     if (cnt == 16) {  // the common case carries no per-element branches: 16 loads in flight
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4);
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4, be);
     } else {
 #pragma unroll
-        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4) : 0u;
+        for (uint32_t e = 0; e < 16; ++e) R.pv[e] = e < cnt ? (uint32_t)sample_from_bytes<BPS>(col + e * rstride, aligned4, be) : 0u;
     }
     R.p1 = R.p2 = 0;
     if (XDELTA) {
         if (s0 + t0 >= 2) {  // same channel, two samples back
-            R.p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4);
-            R.p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4);
+            R.p1 = (uint32_t)sample_from_bytes<BPS>(col - rstride, aligned4, be);
+            R.p2 = (uint32_t)sample_from_bytes<BPS>(col - 2 * rstride, aligned4, be);
         } else {  // channel start: the flat array continues from the end of channel c-1
             const int64_t flat = (int64_t)c * g.ns + s0 + t0;
             R.p1 = (uint32_t)sample_global<BPS>(blk, g, flat - 1);
@@ -434,8 +453,28 @@ __device__ __forceinline__ void load_item_stream(const uint8_t* blk, const Geom&
     }
 }
 // int24: the loaded dwords -> sign-extended samples.  `tail_tile`: the tile that holds the batch's last sample.
+// Big-endian samples (g.be): the loaded dword holds the sample's bytes most significant first; one v_perm_b32 puts them into
+// the top three bytes in little-endian order (from the low three of the dword, or from its top three where the dword was
+// loaded one byte early) and the same arithmetic shift sign-extends.
 template <bool RAGGED>
 __device__ __forceinline__ void stream_fix24(ItemRegs& R, const Geom& g, uint32_t m_nch, uint32_t s0, uint32_t tn, uint32_t lim4, bool tail_tile, uint32_t q) {
+    if (g.be) {
+        const uint32_t rstride = g.nch * 3u;
+        const uint32_t grp = fast_div(q, g.nch, m_nch);
+        const uint32_t c = q - grp * g.nch;
+        const uint32_t off = ((s0 + (grp << 4)) * g.nch + c) * 3u;
+        const uint32_t last = RAGGED ? (min(16u, tn - (grp << 4)) - 1u) * rstride : 0u;
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) {
+            const uint32_t o = off + (RAGGED ? min(e * rstride, last) : e * rstride);
+            const uint32_t early = tail_tile && o > lim4 ? 1u : 0u;  // (loaded one byte early: the sample is the top three bytes)
+            const uint32_t t = early ? __builtin_amdgcn_perm(R.pv[e], R.pv[e], 0x01020303u) : __builtin_amdgcn_perm(R.pv[e], R.pv[e], 0x00010202u);
+            R.pv[e] = (uint32_t)((int32_t)t >> 8);
+        }
+        R.p1 = (uint32_t)((int32_t)__builtin_amdgcn_perm(R.p1, R.p1, 0x00010202u) >> 8);
+        R.p2 = (uint32_t)((int32_t)__builtin_amdgcn_perm(R.p2, R.p2, 0x00010202u) >> 8);
+        return;
+    }
     if (!tail_tile) {
 #pragma unroll
         for (uint32_t e = 0; e < 16; ++e) R.pv[e] = (uint32_t)((int32_t)(R.pv[e] << 8) >> 8);
@@ -454,6 +493,18 @@ __device__ __forceinline__ void stream_fix24(ItemRegs& R, const Geom& g, uint32_
     }
     R.p1 = (uint32_t)((int32_t)(R.p1 << 8) >> 8);
     R.p2 = (uint32_t)((int32_t)(R.p2 << 8) >> 8);
+}
+// int32 / int16 big-endian samples: byte reversal of the landed registers (int16: the load sign-extended the wrong byte)
+template <int BPS>
+__device__ __forceinline__ void stream_swap(ItemRegs& R) {
+    auto sw = [](uint32_t v) -> uint32_t {
+        if (BPS == 4) return __builtin_amdgcn_perm(v, v, 0x00010203u);
+        return (uint32_t)((int32_t)(__builtin_amdgcn_perm(v, v, 0x00010001u) << 16) >> 16);  // bytes 0 and 1 swapped, then sign-extended from 16 bits
+    };
+#pragma unroll
+    for (uint32_t e = 0; e < 16; ++e) R.pv[e] = sw(R.pv[e]);
+    R.p1 = sw(R.p1);
+    R.p2 = sw(R.p2);
 }
 // the set's registers pass through the wait, so nothing that reads them can be scheduled above it
 template <int N>
@@ -624,6 +675,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         const uint32_t q = tid + tj * nthr;
         if (q < t_nitems) {
             if (BPS == 3) stream_fix24<RAGGED>(R, g, m_nch, tc.s0, tc.Tn, lim4_of(tc.b), tc.b + 1 == nblocks && tc.s0 + tc.Tn == g.ns, q);
+            if (BPS != 3 && g.be) stream_swap<BPS>(R);  // (wave-uniform; the registers have landed: nothing of this set is in flight here)
             transform_item<BPS, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
         }
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
@@ -816,7 +868,7 @@ __global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__
     const uint32_t total = g.nch * Tn;
     for (uint32_t q = tid; q < total; q += 256) {
         const uint32_t c = q / Tn, t = q - c * Tn;
-        planar[(size_t)b * g.N + (size_t)c * g.ns + s0 + t] = sample_from_bytes<BPS>(tile + ((size_t)t * g.nch + c) * BPS, aligned4);
+        planar[(size_t)b * g.N + (size_t)c * g.ns + s0 + t] = sample_from_bytes<BPS>(tile + ((size_t)t * g.nch + c) * BPS, aligned4, g.be != 0);
     }
 }
 
@@ -838,7 +890,13 @@ __global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __rest
         uint32_t t = tid / cpr, c4 = tid - t * cpr;
         const int4* in = reinterpret_cast<const int4*>(src + (size_t)b * g.block_bytes + (size_t)s0 * g.nch * 4u);
         for (uint32_t u = tid; u < Tn * cpr; u += 256) {
-            const int4 v = in[u];
+            int4 v = in[u];
+            if (g.be) {  // big-endian samples: the four bytes of every int32 reversed on the way in
+                v.x = (int)__builtin_amdgcn_perm((uint32_t)v.x, (uint32_t)v.x, 0x00010203u);
+                v.y = (int)__builtin_amdgcn_perm((uint32_t)v.y, (uint32_t)v.y, 0x00010203u);
+                v.z = (int)__builtin_amdgcn_perm((uint32_t)v.z, (uint32_t)v.z, 0x00010203u);
+                v.w = (int)__builtin_amdgcn_perm((uint32_t)v.w, (uint32_t)v.w, 0x00010203u);
+            }
             int32_t* r = tile + (4u * c4) * RS + t;
             r[0] = v.x;
             r[RS] = v.y;

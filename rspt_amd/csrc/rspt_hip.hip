@@ -202,8 +202,6 @@ struct rspt_hip_packer {
     uint32_t psel = 0;    // RSPT_PLANESEL (diagnostic builds only): which planes the hzr kernels take; bit 8 / 9: stop behind k_hist / k_tree
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
     int big_endian = 0;   // samples arrive / leave with their bytes reversed (rspt_hip_set_byte_order)
-    uint8_t* swapbuf = nullptr;  // [cap * block_bytes] byte-swapped copy of the input
-    size_t swapbuf_bytes = 0;
 
     // the small-block encoder runs beside the big one (it fills the CUs the persistent grid frees in its tail)
     hipStream_t side = nullptr;
@@ -728,7 +726,6 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_size);
     free_many(p);
     hipFree(p->gat_totals);
-    hipFree(p->swapbuf);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
     if (p->side) {
@@ -828,19 +825,6 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     const uint32_t B = (uint32_t)nblocks;
 
     stamp(p, ST_PRE, st);
-    if (p->big_endian && g.bps > 1) {  // big-endian feed: a byte-reversed copy is what the front end reads
-        const size_t need = nblocks * (size_t)g.block_bytes + 64;
-        if (p->swapbuf_bytes < need) {
-            HIPCHK(p, hipStreamSynchronize(st));
-            hipFree(p->swapbuf);
-            p->swapbuf = nullptr;
-            p->swapbuf_bytes = 0;
-            if (hipMalloc(&p->swapbuf, need) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
-            p->swapbuf_bytes = need;
-        }
-        launch_byteswap(p, src, p->swapbuf, nblocks, st);
-        src = p->swapbuf;
-    }
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     {
         const size_t nhb_call = nblocks * kMaxPlanes * g.nblk;
@@ -1025,6 +1009,7 @@ int rspt_hip_set_nb(rspt_hip_packer* p, unsigned nb) {
 int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian) {
     if (!p) return RSPT_HIP_ERR_ARG;
     p->big_endian = big_endian ? 1 : 0;
+    p->g.be = p->big_endian && p->g.bps > 1 ? 1u : 0u;  // compress: every front end reverses the bytes of a sample as it reads it (no extra pass)
     return RSPT_HIP_OK;
 }
 

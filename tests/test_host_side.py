@@ -254,3 +254,35 @@ def test_cxx_gather_over_rccl(api, tmp_path):
     out = subprocess.run([str(_build_gather_example(tmp_path))], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok" in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,bps,nch,ns,B", [("xdelta_hzr", 3, 64, 65536, 3), ("xdelta_hzr", 4, 64, 65536, 2), ("xdelta_hzr", 2, 64, 65536, 2),
+                                                 ("xdelta_hzr", 3, 5, 20003, 3), ("hzr", 2, 7, 1001, 4), ("xdelta_hzr", 4, 3, 10, 5),
+                                                 ("hadamard", 4, 64, 65536, 1), ("dct", 3, 3, 4096, 2)])
+def test_big_endian_batches_equal_little_endian_ones(api, kind, bps, nch, ns, B):
+    """Big-endian ingest is a flag of the front-end kernels (one v_perm_b32 per loaded sample: no byte-swap pass): full-size
+    int24 / int32 / int16 batches (BASELINE shape; the int24 one ends with the sample whose dword is read one byte early), ragged
+    and tiny shapes of the general kernel, and the transform packers' front ends produce, from the byte-reversed feed, exactly
+    the streams of the little-endian feed -- which the other tests hold to the oracle."""
+    import torch
+
+    from rspt_amd import synth
+
+    le = synth.synth_batch_native(B, nch, ns, first_block=300, bps=bps, ecg=True, device="cuda")
+    be = le.view(B, -1, bps).flip(2).contiguous().view(B, -1)
+    a, b = api.SignalPacker(kind, bps, nch, ns, 2), api.SignalPacker(kind, bps, nch, ns, 2)
+    b.set_byte_order(big_endian=True)
+    d1, s1 = a.compress_batch(le)
+    d2, s2 = b.compress_batch(be)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2) and int(s1.min()) > 0
+    for i in range(B):
+        n = int(s1[i])
+        assert torch.equal(d1[i, :n], d2[i, :n]), i
+    if kind in ("xdelta_hzr", "hzr"):  # and back: the big-endian handle hands big-endian samples back
+        back, used = b.decompress_batch(d2, B, d2.shape[1])
+        torch.cuda.synchronize()
+        assert torch.equal(used, s2) and torch.equal(back.view(B, -1), be)
+    a.close()
+    b.close()
