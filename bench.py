@@ -49,8 +49,11 @@ def parse_args(argv=None):
     ap.add_argument("--nb", type=int, default=3)
     ap.add_argument("--bps", type=int, default=4, choices=[1, 2, 3, 4], help="bytes per sample of the input (the metric is quoted on 4)")
     ap.add_argument("--packer", default="xdelta_hzr", choices=["xdelta_hzr", "hzr", "hadamard", "dct"])
-    ap.add_argument("--op", default="compress", choices=["compress", "decompress"],
-                    help="decompress: the timed step decodes the streams of one batch (secondary line, c3 workload, one GPU)")
+    ap.add_argument("--op", default="compress", choices=["compress", "decompress", "prefilter"],
+                    help="decompress: the timed step decodes the streams of one batch (secondary line, c3 workload, one GPU); "
+                         "prefilter: the IIR pre-filter stage in front of the packers (rspt_hip_iir_prefilter_batch_dev)")
+    ap.add_argument("--iir-mode", default="per_channel", choices=["per_channel", "shared"],
+                    help="prefilter: a fresh filter per channel, or the harness's one filter object whose state runs on from channel to channel")
     ap.add_argument("--big-endian", action="store_true", help="feed the samples most significant byte first (rspt_hip_set_byte_order)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL exchange altogether")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -191,6 +194,77 @@ def cpu_baseline(args, sample_native):
     }
 
 
+# the harness's band-pass (0.4-200 Hz Butterworth @ 2000 Sps, lib_rspt_test/rspt_test.cpp:123-125) and its history length (:129)
+IIR_N = [1.00000000000, -3.14332095199, 3.70064088865, -1.97083923944, 0.41351972908]
+IIR_D = [0.06722876941, 0.00000000000, -0.13445753881, 0.00000000000, 0.06722876941]
+IIR_INIT = 2000
+F64_DEP_NS = 2.0  # one dependent v_mul_f64 / v_add_f64 of a wave alone on its SIMD: 2.0 ns = the interval at which a lone wave issues at all (tools/issue_rate.hip, profiles/r03_issue_rate.txt)
+
+
+def bench_prefilter(args):
+    """Secondary line: the IIR pre-filter step of the reference's pipeline (rspt_test.cpp:116-136) on a device-resident batch.
+    The bound is neither HBM nor MFMA but a serial fp64 recurrence: per sample one product and NC - 1 subtractions that each
+    need the one before (filter_opt, iir_filter.cpp:79-104), NC = 5 here; the history initialisation (4 * 2000 calls of
+    filter(), :106-110) is a chain of one product and 2 (NC - 1) - 1 sums per call.  `roofline.chain_floor_ms` is that chain
+    at the measured latency of a dependent fp64 instruction; per-channel mode runs the channels of all blocks side by side,
+    shared mode (bit-exact with the harness) chains the channels of a block behind one another."""
+    import torch
+
+    from rspt_amd import api, synth
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    api.lib()
+    nch, ns, B, bps = args.nch, args.ns, args.blocks, args.bps
+    pk = api.SignalPacker("xdelta_hzr", bps, nch, ns, args.nb)
+    src = synth.synth_batch_native(B, nch, ns, first_block=0, bps=bps, ecg=True, device=dev)
+    work = src.clone()
+    per_channel = args.iir_mode == "per_channel"
+    # check first (outside the timed region): blocks 0 and B-1 against the CPU restatement of the same mode
+    pk.iir_prefilter_batch(work, IIR_N, IIR_D, IIR_INIT, per_channel=per_channel)
+    torch.cuda.synchronize()
+    verified = None
+    if not args.no_verify:
+        from oracle.oracle import Oracle
+
+        orc = Oracle()
+        verified = True
+        for b in sorted({0, B - 1}):
+            want = orc.iir_prefilter(src[b].cpu().numpy(), bps, nch, ns, IIR_N, IIR_D, IIR_INIT, shared_state=not per_channel)
+            verified = verified and work[b].cpu().numpy().tobytes() == want
+    for _ in range(args.warmup):
+        pk.iir_prefilter_batch(work, IIR_N, IIR_D, IIR_INIT, per_channel=per_channel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pk.iir_prefilter_batch(work, IIR_N, IIR_D, IIR_INIT, per_channel=per_channel)  # (in place: every step filters the previous step's output)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    nc = len(IIR_N)
+    # instructions the wave that holds a channel's filter state cannot hand to anyone else: per sample the NC - 1 feedback products and
+    # NC - 1 subtractions of filter_opt; per history call of filter() NC - 1 products and 2 (NC - 1) sums (its feed-forward products are constants)
+    ops = ns * 2 * (nc - 1) + 4 * IIR_INIT * 3 * (nc - 1)
+    floor_ms = ops * F64_DEP_NS * 1e-6 * (1 if per_channel else nch)
+    alg = 2 * B * pk.block_bytes  # read and written once
+    res = {
+        "metric": "MSamples/s prefilter (iir band-pass nc=5, %dch x %d int%d, %s)" % (nch, ns, 8 * bps, args.iir_mode),
+        "value": round(B * nch * ns * args.steps / dt / 1e6, 1), "unit": "MSamples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic (SURVEY 8d, ECG-like variant)",
+        "verified": verified,
+        "config": {"workload": "iir pre-filter of %d blocks of %dch x %d int%d, in place, device-resident; mode %s" % (B, nch, ns, 8 * bps, args.iir_mode),
+                   "coefficients": "band-pass of rspt_test.cpp:123-125 (5 coefficients), init_history_values(first sample, %d)" % IIR_INIT},
+        "roofline": {"bound": "hbm", "kernel": "k_iir", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "true_bound": "serial fp64 recurrence, not bandwidth",
+                     "recurrence_instructions_per_channel": ops, "dependent_f64_instruction_ns": F64_DEP_NS,
+                     "chain_floor_ms": round(floor_ms, 3), "ms_over_chain_floor": round(ms / floor_ms, 2)},
+    }
+    print(json.dumps(res), flush=True)
+    pk.close()
+    return 0 if verified is not False else 3
+
+
 def kernels_sha():
     """fingerprint of the kernel sources: counters collected on other sources are stale"""
     h = hashlib.sha256()
@@ -206,6 +280,9 @@ def main():
     args = parse_args()
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+
+    if args.op == "prefilter":
+        sys.exit(bench_prefilter(args))
 
     import torch
 

@@ -361,6 +361,23 @@ static void launch_byteswap(rspt_hip_packer* p, const uint8_t* src, uint8_t* dst
 template <int BPS, int NC>
 static void launch_iir(rspt_hip_packer* p, uint8_t* buf, uint32_t B, const IirCoef& c, int per_channel, hipStream_t st) {
     const Geom& g = p->g;
+    if (g.ns >= kIirChunk && c.init_steps >= NC - 1) {  // the pipelined form: recurrence, feed-forward sums and stores on waves of their own
+        const bool al = (BPS == 4 || BPS == 2) && (reinterpret_cast<uintptr_t>(buf) % BPS) == 0;  // (block_bytes is a multiple of BPS)
+        if (per_channel) {
+            const uint32_t units = B * g.nch;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((units + 63) / 64), dim3(kIirThreads), 0, st, buf, g.nch, g.ns, (uint64_t)g.block_bytes, c, B, 64u); };
+            if (al) go(&k_iir_pipe<BPS, NC, false, (BPS == 4 || BPS == 2)>);
+            else go(&k_iir_pipe<BPS, NC, false, false>);
+        } else {
+            // shared mode: lane <-> block; few lanes per workgroup so that the blocks' scattered accesses spread over the CUs
+            uint32_t lpw = (B + (uint32_t)p->num_cu - 1) / (uint32_t)p->num_cu;
+            lpw = lpw < 1 ? 1 : lpw > 64 ? 64 : lpw;
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((B + lpw - 1) / lpw), dim3(kIirThreads), 0, st, buf, g.nch, g.ns, (uint64_t)g.block_bytes, c, B, lpw); };
+            if (al) go(&k_iir_pipe<BPS, NC, true, (BPS == 4 || BPS == 2)>);
+            else go(&k_iir_pipe<BPS, NC, true, false>);
+        }
+        return;
+    }
     if (per_channel) {
         const uint32_t threads = B * g.nch;
         hipLaunchKernelGGL((k_iir<BPS, NC, false>), dim3((threads + 63) / 64), dim3(64), 0, st, buf, g.nch, g.ns, (uint64_t)g.block_bytes, c, B);

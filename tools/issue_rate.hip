@@ -173,6 +173,15 @@ DEF_HOT(t_ds_add_hot4, 4)
 DEF_HOT(t_ds_add_hot8, 8)
 DEF_HOT(t_ds_add_hot16, 16)
 
+// ---- fp64: the IIR pre-filter's recurrence is a chain of dependent v_mul_f64 / v_add_f64 (filter.hip): latency and issue rate
+DEF_TEST(t_f64_add_dep, R32("v_add_f64 %[p0], %[p0], %[p1]\n"), "memory")
+DEF_TEST(t_f64_mul_dep, R32("v_mul_f64 %[p0], %[p0], %[p1]\n"), "memory")
+DEF_TEST(t_f64_muladd_dep, R8("v_mul_f64 %[p2], %[p0], %[p1]\n v_add_f64 %[p0], %[p3], -%[p2]\n v_add_f64 %[p0], %[p0], -%[p1]\n v_add_f64 %[p0], %[p0], -%[p3]\n"), "memory")
+DEF_TEST(t_f64_add, R8("v_add_f64 %[p0], %[p0], %[p1]\n v_add_f64 %[p1], %[p1], %[p2]\n v_add_f64 %[p2], %[p2], %[p3]\n v_add_f64 %[p3], %[p3], %[p0]\n"), "memory")
+DEF_TEST(t_f64_mul, R8("v_mul_f64 %[p0], %[p0], %[p1]\n v_mul_f64 %[p1], %[p1], %[p2]\n v_mul_f64 %[p2], %[p2], %[p3]\n v_mul_f64 %[p3], %[p3], %[p0]\n"), "memory")
+DEF_TEST(t_f32_fma, R4("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %4\n v_fma_f32 %3, %3, %4, %5\n"
+                       "v_fma_f32 %4, %4, %5, %6\n v_fma_f32 %5, %5, %6, %7\n v_fma_f32 %6, %6, %7, %0\n v_fma_f32 %7, %7, %0, %1\n"), "memory")
+
 typedef void (*kern_t)(unsigned long long*, unsigned*);
 static void run(const char* name, kern_t k, int threads, int per_rep) {
     const int nwg = 512;
@@ -201,8 +210,11 @@ static void run(const char* name, kern_t k, int threads, int per_rep) {
     const double cyc = (double)v[v.size() / 2];
     const int waves_cu = 2 * threads / 64;
     const double ipc = (double)per_rep * REPS * waves_cu / cyc;
-    printf("%-18s threads %4d  waves/CU %2d  median wave cycles %9.0f  -> %.3f wave-instr/cycle/CU  (%.2f cycles per instr per SIMD)  wall %.3f ms\n", name,
-           threads, waves_cu, cyc, ipc, 4.0 / ipc, ms);
+    // wall-clock view (s_memtime ticks turned out to run at about half the shader clock on this part): instructions per ns and CU,
+    // and the time one wave needs per instruction (the latency of a dependent chain when the wave is alone on its SIMD)
+    const double per_cu_ns = (double)per_rep * REPS * waves_cu / (ms * 1e6), ns_per_wave_instr = ms * 1e6 / ((double)per_rep * REPS);
+    printf("%-18s threads %4d  waves/CU %2d  ticks %9.0f -> %.3f instr/tick/CU | wall %.3f ms -> %.3f instr/ns/CU, %.2f ns per instr of one wave\n", name,
+           threads, waves_cu, cyc, ipc, ms, per_cu_ns, ns_per_wave_instr);
     hipFree(out);
     hipFree(sink);
 }
@@ -213,6 +225,8 @@ int main() {
     RUN(t_v_mad_u24) RUN(t_v_lshl64) RUN(t_v_bcnt) RUN(t_v_ffbl) RUN(t_v_sdwa) RUN(t_v_dpp) RUN(t_v_min_dpp)
     RUN(t_v_cmp_vcc) RUN(t_v_cmp_sgpr) RUN(t_v_cmp_sdwa) RUN(t_v_cndmask) RUN(t_v_readlane)
     RUN(t_s_and64) RUN(t_s_add32) RUN(t_mix_1v1s) RUN(t_mix_3v1s)
+    RUN(t_f32_fma) RUN(t_f64_add) RUN(t_f64_mul) RUN(t_f64_add_dep) RUN(t_f64_mul_dep) RUN(t_f64_muladd_dep)
+    run("t_f64_add_dep", t_f64_add_dep, 64, 32); run("t_f64_muladd_dep", t_f64_muladd_dep, 64, 32); run("t_v_xor_dep", t_v_xor_dep, 64, 32); run("t_v_perm_dep", t_v_perm_dep, 64, 32);
     RUN(t_v_cndmask_sg) RUN(t_v_cndmask_c) RUN(t_v_cmp_cnd) RUN(t_v_and_sgpr) RUN(t_v_lshl_sgpr) RUN(t_v_add_co) RUN(t_v_addc) RUN(t_v_add) RUN(t_v_or) RUN(t_v_min)
     RUN(t_v_mov) RUN(t_v_and_or) RUN(t_v_xor_dep) RUN(t_v_perm_dep) RUN(t_v_mbcnt) RUN(t_v_rfl) RUN(t_s_bit64) RUN(t_s_nop)
     RUN(t_ds_add_hot1) RUN(t_ds_add_hot2) RUN(t_ds_add_hot4) RUN(t_ds_add_hot8) RUN(t_ds_add_hot16)
