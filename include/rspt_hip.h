@@ -50,7 +50,8 @@ enum rspt_hip_status {
     RSPT_HIP_ERR_LAUNCH = -4,      /* a HIP call or kernel launch failed (see rspt_hip_last_hip_error) */
     RSPT_HIP_ERR_DST_TOO_SMALL = -5, /* compressed block does not fit dst_max_len / dst_stride */
     RSPT_HIP_ERR_CORRUPT = -6,     /* decompress: malformed stream */
-    RSPT_HIP_ERR_UNSUPPORTED = -7  /* shape outside what the kernels handle (documented in DESIGN.md) */
+    RSPT_HIP_ERR_UNSUPPORTED = -7, /* shape outside what the kernels handle (documented in DESIGN.md) */
+    RSPT_HIP_ERR_BUSY = -8         /* rspt_hip_feed_push: every slot of the feed is in flight (poll, then push again) */
 };
 
 const char* rspt_hip_status_string(int status);
@@ -134,6 +135,31 @@ int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblo
  * that does not decode: consumed[i] = 0 and the call returns RSPT_HIP_ERR_CORRUPT after finishing the others. */
 int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t src_stride, const size_t* src_len, size_t nblocks, void* dst_host,
                              size_t* consumed);
+
+/* ---- a feed of blocks that arrive over time (the acquisition side: lib_ring_buffer/ring_buffers.h:150-203 io_buffer hands
+ * a consumer one filled buffer after the other; the consumer's loop is rspt_test.cpp:66-72, one compress() per block) ----------
+ * Non-blocking: push a block when it is there, poll for finished streams when convenient.  Behind it the same three-stage
+ * pipeline as rspt_hip_compress_many (upload | compress | download on three HIP streams), over a ring of `slots` groups of
+ * `blocks_per_launch` blocks; the streams are byte for byte those of successive compress() calls in push order (the nb state
+ * moves from block to block).
+ *   rspt_hip_feed_begin   allocate the ring (slots >= 2; blocks_per_launch >= 1: 1 = lowest latency, more = higher rate)
+ *   rspt_hip_feed_push    queue one block: src_host (rspt_hip_block_bytes() bytes; page-locked memory from rspt_hip_host_alloc
+ *                         uploads by DMA) -> its stream will be written to dst_host (dst_cap bytes).  Both must stay valid
+ *                         until the block is reported by rspt_hip_feed_poll.  Returns RSPT_HIP_OK, or RSPT_HIP_ERR_BUSY when
+ *                         every slot is in flight (poll, then push again) -- it never waits.  A group is launched when it is
+ *                         full; rspt_hip_feed_submit launches a partly filled one (when no more blocks are expected soon).
+ *   rspt_hip_feed_poll    report ONE finished block, in push order: returns 1 and sets *seq (0, 1, 2, ... in push order),
+ *                         *dst_len and *status (RSPT_HIP_OK, or RSPT_HIP_ERR_DST_TOO_SMALL with *dst_len = the size needed
+ *                         and nothing copied); returns 0 when none is ready yet; never waits.
+ *   rspt_hip_feed_flush   submit what is queued and wait until everything pushed so far can be polled
+ *   rspt_hip_feed_end     flush, drop unpolled results, free the ring.
+ * One feed per handle; the batch entry points must not be called on the handle while a feed is open. */
+int rspt_hip_feed_begin(rspt_hip_packer* p, size_t blocks_per_launch, size_t slots);
+int rspt_hip_feed_push(rspt_hip_packer* p, const void* src_host, void* dst_host, size_t dst_cap);
+int rspt_hip_feed_submit(rspt_hip_packer* p);
+int rspt_hip_feed_poll(rspt_hip_packer* p, size_t* seq, size_t* dst_len, int* status);
+int rspt_hip_feed_flush(rspt_hip_packer* p);
+int rspt_hip_feed_end(rspt_hip_packer* p);
 
 /* ---- device-resident, batched forms (bench, multi-GPU shards) ------------ */
 

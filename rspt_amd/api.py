@@ -26,6 +26,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
     "rspt_hip_compress_many", "rspt_hip_decompress_many", "rspt_hip_gather_sizes", "rspt_hip_gather_payload", "rspt_hip_gather_containers",
+    "rspt_hip_feed_begin", "rspt_hip_feed_push", "rspt_hip_feed_submit", "rspt_hip_feed_poll", "rspt_hip_feed_flush", "rspt_hip_feed_end",
 ]
 
 _u8p = C.POINTER(C.c_uint8)
@@ -107,6 +108,12 @@ def lib():
     L.rspt_hip_iir_prefilter_batch_dev.restype = C.c_int
     L.rspt_hip_iir_prefilter_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int,
                                                    C.c_int, C.c_void_p]
+    L.rspt_hip_feed_begin.restype, L.rspt_hip_feed_begin.argtypes = C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]
+    L.rspt_hip_feed_push.restype, L.rspt_hip_feed_push.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.rspt_hip_feed_submit.restype, L.rspt_hip_feed_submit.argtypes = C.c_int, [C.c_void_p]
+    L.rspt_hip_feed_poll.restype, L.rspt_hip_feed_poll.argtypes = C.c_int, [C.c_void_p, _szp, _szp, C.POINTER(C.c_int)]
+    L.rspt_hip_feed_flush.restype, L.rspt_hip_feed_flush.argtypes = C.c_int, [C.c_void_p]
+    L.rspt_hip_feed_end.restype, L.rspt_hip_feed_end.argtypes = C.c_int, [C.c_void_p]
     # the C++ factories behind the same library (include/signal_packer.h), via their C shim
     L.rspt_cxx_new.restype, L.rspt_cxx_new.argtypes = C.c_void_p, [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t]
     L.rspt_cxx_delete.restype, L.rspt_cxx_delete.argtypes = None, [C.c_int, C.c_void_p]
@@ -179,6 +186,37 @@ class SignalPacker:
         if rc != -5 or raise_on_small:  # RSPT_HIP_ERR_DST_TOO_SMALL: the lengths say which streams
             self._check("rspt_hip_compress_many", rc)
         return np.array(lens[:], dtype=np.int64)
+
+    # -- a feed of blocks that arrive over time (rspt_hip_feed_*): push when a block is there, poll for finished streams ----
+    def feed_begin(self, blocks_per_launch=1, slots=3):
+        self._check("rspt_hip_feed_begin", self._L.rspt_hip_feed_begin(self._h, blocks_per_launch, slots))
+
+    def feed_push(self, src, dst):
+        """queue one block (uint8 arrays that stay alive until the block is polled); False: the ring is full, poll first"""
+        rc = self._L.rspt_hip_feed_push(self._h, src.ctypes.data, dst.ctypes.data, dst.size)
+        if rc == -8:  # RSPT_HIP_ERR_BUSY
+            return False
+        self._check("rspt_hip_feed_push", rc)
+        return True
+
+    def feed_submit(self):
+        self._check("rspt_hip_feed_submit", self._L.rspt_hip_feed_submit(self._h))
+
+    def feed_poll(self):
+        """-> (seq, length, status) of one finished block in push order, or None when none is ready (never waits)"""
+        seq, n, st = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+        rc = self._L.rspt_hip_feed_poll(self._h, C.byref(seq), C.byref(n), C.byref(st))
+        if rc == 0:
+            return None
+        if rc != 1:
+            self._check("rspt_hip_feed_poll", rc)
+        return seq.value, n.value, st.value
+
+    def feed_flush(self):
+        self._check("rspt_hip_feed_flush", self._L.rspt_hip_feed_flush(self._h))
+
+    def feed_end(self):
+        self._check("rspt_hip_feed_end", self._L.rspt_hip_feed_end(self._h))
 
     def decompress_many(self, streams, out, lengths=None):
         """streams = uint8 array [n, stride] (one stream per row), out = uint8 array of n * block_bytes -> bytes consumed per stream

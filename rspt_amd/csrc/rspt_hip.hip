@@ -102,6 +102,8 @@ const char* kStageNames[ST_COUNT] = {"preprocess", "nb_scan", "hzr_hist", "hzr_t
 
 }  // namespace
 
+struct Feed;
+
 struct rspt_hip_packer {
     Geom g{};
     int device = 0;
@@ -185,6 +187,7 @@ struct rspt_hip_packer {
     uint64_t* m_hsizes = nullptr;             // page-locked host, 2 x chunk
     uint64_t* m_idx[2] = {nullptr, nullptr};  // device: [4 + 2 x chunk] a container header + index over a slot's streams (decompress_many with src_len)
     uint64_t* m_hidx = nullptr;               // page-locked host, 2 x (4 + 2 x chunk)
+    struct Feed* feed = nullptr;              // rspt_hip_feed_*: a ring of block groups in flight
     uint64_t* gat_totals = nullptr;           // device [gat_world]: container lengths of all ranks (rspt_hip_gather_containers)
     int gat_world = 0;
     size_t m_chunk = 0, m_stride = 0;
@@ -416,6 +419,7 @@ const char* rspt_hip_status_string(int s) {
         case RSPT_HIP_ERR_DST_TOO_SMALL: return "destination too small for the compressed stream";
         case RSPT_HIP_ERR_CORRUPT: return "malformed stream";
         case RSPT_HIP_ERR_UNSUPPORTED: return "shape not supported by the kernels";
+        case RSPT_HIP_ERR_BUSY: return "every slot of the feed is in flight";
         default: return "unknown status";
     }
 }
@@ -741,6 +745,7 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipFree(p->h_src);
     hipFree(p->h_dst);
     hipFree(p->h_size);
+    if (p->feed) rspt_hip_feed_end(p);
     free_many(p);
     hipFree(p->gat_totals);
     for (int i = 0; i <= ST_COUNT; ++i)
@@ -1187,6 +1192,200 @@ static int compress_many_pipeline(rspt_hip_packer* p, const void* src_host, size
     HIPCHK(p, hipStreamSynchronize(p->m_down));
     if (nb_now >= 1 && nb_now <= 4) p->nb_host = nb_now;
     return too_small ? RSPT_HIP_ERR_DST_TOO_SMALL : RSPT_HIP_OK;
+}
+
+// ---- rspt_hip_feed_*: blocks that arrive over time ---------------------------------------------------------------------------
+struct FeedSlot {
+    enum State { FREE, FILLING, COMPRESSING, DOWNLOADING, DONE } state = FREE;
+    uint8_t* d_src = nullptr;
+    uint8_t* d_dst = nullptr;
+    uint64_t* d_sizes = nullptr;
+    uint64_t* h_sizes = nullptr;  // page-locked: [G] stream lengths + [1] nb_state behind this group
+    std::vector<void*> dst_host;
+    std::vector<size_t> dst_cap;
+    size_t count = 0, delivered = 0, first_seq = 0;
+    hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
+};
+struct Feed {
+    size_t G = 0, stride = 0;
+    std::vector<FeedSlot> slots;
+    size_t head = 0, tail = 0;  // ring positions: oldest slot not yet FREE; the slot being filled / filled next
+    size_t next_seq = 0;
+};
+
+static void feed_free(rspt_hip_packer* p) {
+    Feed* f = p->feed;
+    if (!f) return;
+    for (auto& s : f->slots) {
+        hipFree(s.d_src);
+        hipFree(s.d_dst);
+        hipFree(s.d_sizes);
+        if (s.h_sizes) hipHostFree(s.h_sizes);
+        if (s.ev_up) hipEventDestroy(s.ev_up);
+        if (s.ev_comp) hipEventDestroy(s.ev_comp);
+        if (s.ev_down) hipEventDestroy(s.ev_down);
+    }
+    delete f;
+    p->feed = nullptr;
+}
+
+int rspt_hip_feed_begin(rspt_hip_packer* p, size_t blocks_per_launch, size_t slots) {
+    if (!p || blocks_per_launch == 0 || blocks_per_launch > 4096 || slots < 2 || slots > 64 || p->feed) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    if (!p->m_up && hipStreamCreateWithFlags(&p->m_up, hipStreamNonBlocking) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+    if (!p->m_down && hipStreamCreateWithFlags(&p->m_down, hipStreamNonBlocking) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+    int rc = rspt_hip_reserve(p, blocks_per_launch);
+    if (rc) return rc;
+    Feed* f = new (std::nothrow) Feed();
+    if (!f) return RSPT_HIP_ERR_ALLOC;
+    p->feed = f;
+    f->G = blocks_per_launch;
+    f->stride = (rspt_hip_max_compressed_size(p) + 255) & ~(size_t)255;
+    f->slots.resize(slots);
+    bool ok = true;
+    for (auto& s : f->slots) {
+        ok &= hipMalloc(&s.d_src, f->G * p->g.block_bytes + 64) == hipSuccess;
+        ok &= hipMalloc(&s.d_dst, f->G * f->stride) == hipSuccess;
+        ok &= hipMalloc(&s.d_sizes, f->G * sizeof(uint64_t)) == hipSuccess;
+        ok &= hipHostMalloc((void**)&s.h_sizes, (f->G + 1) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&s.ev_up, hipEventDisableTiming) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&s.ev_comp, hipEventDisableTiming) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&s.ev_down, hipEventDisableTiming) == hipSuccess;
+        s.dst_host.resize(f->G);
+        s.dst_cap.resize(f->G);
+    }
+    if (!ok) {
+        feed_free(p);
+        return RSPT_HIP_ERR_ALLOC;
+    }
+    return RSPT_HIP_OK;
+}
+
+static int feed_launch(rspt_hip_packer* p, FeedSlot& s) {
+    Feed* f = p->feed;
+    HIPCHK(p, hipEventRecord(s.ev_up, p->m_up));
+    HIPCHK(p, hipStreamWaitEvent(p->stream, s.ev_up, 0));
+    const int rc = rspt_hip_compress_batch_dev(p, s.d_src, s.count, s.d_dst, f->stride, s.d_sizes, (void*)p->stream);
+    if (rc) return rc;
+    HIPCHK(p, hipMemcpyAsync(s.h_sizes, s.d_sizes, s.count * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(p, hipMemcpyAsync(s.h_sizes + f->G, p->nb_state, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(p, hipEventRecord(s.ev_comp, p->stream));
+    s.state = FeedSlot::COMPRESSING;
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_feed_submit(rspt_hip_packer* p) {
+    if (!p || !p->feed) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    Feed* f = p->feed;
+    FeedSlot& s = f->slots[f->tail];
+    if (s.state != FeedSlot::FILLING || s.count == 0) return RSPT_HIP_OK;
+    const int rc = feed_launch(p, s);
+    f->tail = (f->tail + 1) % f->slots.size();
+    return rc;
+}
+
+int rspt_hip_feed_push(rspt_hip_packer* p, const void* src_host, void* dst_host, size_t dst_cap) {
+    if (!p || !p->feed || !src_host || !dst_host) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    Feed* f = p->feed;
+    FeedSlot& s = f->slots[f->tail];
+    if (s.state != FeedSlot::FREE && s.state != FeedSlot::FILLING) return RSPT_HIP_ERR_BUSY;  // the ring is full: poll first
+    if (s.state == FeedSlot::FREE) {
+        s.state = FeedSlot::FILLING;
+        s.count = s.delivered = 0;
+        s.first_seq = f->next_seq;
+    }
+    const size_t i = s.count;
+    HIPCHK(p, hipMemcpyAsync(s.d_src + i * p->g.block_bytes, src_host, p->g.block_bytes, hipMemcpyHostToDevice, p->m_up));
+    s.dst_host[i] = dst_host;
+    s.dst_cap[i] = dst_cap;
+    ++s.count;
+    ++f->next_seq;
+    if (s.count == f->G) return rspt_hip_feed_submit(p);
+    return RSPT_HIP_OK;
+}
+
+// move every slot as far as it can go without waiting (wait = true: wait for each step instead)
+static int feed_advance(rspt_hip_packer* p, bool wait) {
+    Feed* f = p->feed;
+    const size_t n = f->slots.size();
+    for (size_t k = 0; k < n; ++k) {
+        FeedSlot& s = f->slots[(f->head + k) % n];
+        if (s.state == FeedSlot::COMPRESSING) {
+            if (wait) HIPCHK(p, hipEventSynchronize(s.ev_comp));
+            const hipError_t q = hipEventQuery(s.ev_comp);
+            if (q == hipErrorNotReady) break;  // (the slots behind it are not further along: one compute stream)
+            if (q != hipSuccess) {
+                p->last_hip_error = (int)q;
+                return RSPT_HIP_ERR_LAUNCH;
+            }
+            const uint32_t nb_now = (uint32_t)s.h_sizes[f->G];
+            if (nb_now >= 1 && nb_now <= 4 && nb_now > p->nb_host) p->nb_host = nb_now;  // the next launch writes exactly the planes it needs
+            HIPCHK(p, hipStreamWaitEvent(p->m_down, s.ev_comp, 0));
+            for (size_t i = 0; i < s.count; ++i) {
+                const uint64_t sz = s.h_sizes[i];
+                if (!(sz >> 63) && sz <= s.dst_cap[i])
+                    HIPCHK(p, hipMemcpyAsync(s.dst_host[i], s.d_dst + i * f->stride, (size_t)sz, hipMemcpyDeviceToHost, p->m_down));
+            }
+            HIPCHK(p, hipEventRecord(s.ev_down, p->m_down));
+            s.state = FeedSlot::DOWNLOADING;
+        }
+        if (s.state == FeedSlot::DOWNLOADING) {
+            if (wait) HIPCHK(p, hipEventSynchronize(s.ev_down));
+            const hipError_t q = hipEventQuery(s.ev_down);
+            if (q == hipErrorNotReady) continue;  // (a later slot's compress may still be ready for its downloads)
+            if (q != hipSuccess) {
+                p->last_hip_error = (int)q;
+                return RSPT_HIP_ERR_LAUNCH;
+            }
+            s.state = FeedSlot::DONE;
+        }
+    }
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_feed_poll(rspt_hip_packer* p, size_t* seq, size_t* dst_len, int* status) {
+    if (!p || !p->feed || !seq || !dst_len || !status) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    Feed* f = p->feed;
+    const int rc = feed_advance(p, false);
+    if (rc) return rc;
+    FeedSlot& s = f->slots[f->head];
+    if (s.state != FeedSlot::DONE) return 0;
+    const size_t i = s.delivered;
+    const uint64_t sz = s.h_sizes[i];
+    *seq = s.first_seq + i;
+    if ((sz >> 63) || sz > s.dst_cap[i]) {
+        *dst_len = (sz >> 63) ? 0 : (size_t)sz;
+        *status = RSPT_HIP_ERR_DST_TOO_SMALL;
+    } else {
+        *dst_len = (size_t)sz;
+        *status = RSPT_HIP_OK;
+    }
+    if (++s.delivered == s.count) {
+        s.state = FeedSlot::FREE;
+        f->head = (f->head + 1) % f->slots.size();
+    }
+    return 1;
+}
+
+int rspt_hip_feed_flush(rspt_hip_packer* p) {
+    if (!p || !p->feed) return RSPT_HIP_ERR_ARG;
+    int rc = rspt_hip_feed_submit(p);
+    if (rc) return rc;
+    return feed_advance(p, true);
+}
+
+int rspt_hip_feed_end(rspt_hip_packer* p) {
+    if (!p || !p->feed) return RSPT_HIP_ERR_ARG;
+    hipSetDevice(p->device);
+    rspt_hip_feed_submit(p);
+    hipStreamSynchronize(p->m_up);
+    hipStreamSynchronize(p->stream);
+    hipStreamSynchronize(p->m_down);  // nothing is copying from or into the caller's buffers any more
+    feed_free(p);
+    return RSPT_HIP_OK;
 }
 
 static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,

@@ -286,3 +286,62 @@ def test_big_endian_batches_equal_little_endian_ones(api, kind, bps, nch, ns, B)
         assert torch.equal(used, s2) and torch.equal(back.view(B, -1), be)
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group,slots,pinned", [(1, 2, True), (4, 3, False), (3, 2, True)])
+def test_feed_equals_a_loop_of_compress_calls(api, orc, group, slots, pinned):
+    """rspt_hip_feed_*: blocks pushed one by one as they "arrive", finished streams polled whenever convenient -- never a blocking
+    call until the final flush -- == the oracle's packer fed the same blocks one compress() call after the other (the amplitudes
+    step up in the middle: nb escalates inside a group; one destination is too small and is reported, not written)"""
+    nch, ns, bps, n = 8, 2048, 4, 23
+    blocks = [cases._rand_native(nch, ns, bps, 5000 + i, 2000 if i < 9 else 1 << 27, walk=bool(i & 1)) for i in range(n)]
+    po = orc.packer("xdelta_hzr", bps, nch, ns, 2)
+    want = [po.compress(b) for b in blocks]
+    pk = api.new_xdelta_hzr(bps, nch, ns, 2)
+    cap = pk.max_compressed_size
+    bufs = []
+    if pinned:
+        src = [api.HostBuffer(pk.block_bytes) for _ in range(n)]
+        for s_, b in zip(src, blocks):
+            s_.a[:] = b
+        dst = [api.HostBuffer(cap) for _ in range(n)]
+        bufs = src + dst
+        src_a, dst_a = [s_.a for s_ in src], [d.a for d in dst]
+    else:
+        src_a, dst_a = [b.copy() for b in blocks], [np.zeros(cap, dtype=np.uint8) for _ in range(n)]
+    small = 5
+    dst_a[small] = dst_a[small][:16]  # too small for its stream
+    got = {}
+
+    def drain():
+        while True:
+            r = pk.feed_poll()
+            if r is None:
+                return
+            got[r[0]] = r[1:]
+
+    pk.feed_begin(group, slots)
+    for i in range(n):
+        while not pk.feed_push(src_a[i], dst_a[i]):  # ring full: take what is finished, then try again
+            drain()
+        if i % 5 == 4:
+            drain()
+        if i == 11:
+            pk.feed_submit()  # a partly filled group goes out when nothing more is expected for a while
+    pk.feed_flush()
+    drain()
+    assert sorted(got) == list(range(n))
+    for i in range(n):
+        ln, st = got[i]
+        if i == small:
+            assert st == -5 and ln == len(want[i])
+        else:
+            assert st == 0 and dst_a[i][:ln].tobytes() == want[i], i
+    assert pk.feed_poll() is None
+    pk.feed_end()
+    # the handle is an ordinary packer again, its nb state where the feed left it
+    assert pk.nb == orc.packer_nb(po) and pk.compress(blocks[0]) == po.compress(blocks[0])
+    pk.close()
+    for b in bufs:
+        b.close()
