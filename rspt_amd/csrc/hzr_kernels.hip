@@ -170,38 +170,85 @@ __device__ __forceinline__ void small_block_hist(const uint8_t* __restrict__ in,
     if (pend && l == 0) run_count(h, pend);
 }
 
-// The merge loop with the live keys in NREG = ceil(S/64) registers per lane.  Each iteration extracts the
-// two smallest keys = the reference's `<=` scan (hzr_encode.c:251-260): count ascending, index descending.
-// The key carries the node index, so where a key is parked is free: the parent takes the register slot of
-// its second child and the slot of the first one stays empty; S slots are enough for the whole build.
-// Nothing is read back from LDS inside the loop (lane 0 only posts the two up-links).
-template <int NREG>
-__device__ __forceinline__ void merge_loop(TreeLds& t, uint32_t S) {
+// The merge loop with the live keys kept SORTED (descending) across lanes and registers: element e lives in lane e % 64 of
+// register e / 64, the n live ones are elements 0 .. n-1, so the two smallest keys -- the reference's `<=` scan picks exactly
+// them (hzr_encode.c:251-260: count ascending, node index descending = key ascending) -- are simply elements n-1 and n-2: two
+// v_readlane instead of two wave-wide reductions.  Popping them is n -= 2 (nothing moves); the parent's key goes to its place
+// among the rest by ONE lane shift of the elements below it:
+//     new[e] = old[e] > nk ? old[e] : (old[e-1] > nk ? nk : old[e-1])            (old[-1] = +inf)
+// (what lies at or beyond n is stale and never read again: n only shrinks).  k_tree is bound by vector issue, not by latency
+// (profiles/r03_notes.md: 0.9 vector instructions per cycle and CU, nearly all of them the reductions' half-rate DPP steps):
+// per merge this is 2 + 5 per live register instructions against the 54 .. 76 of round 2's form (the live keys unordered in
+// ceil(S/64) registers, two DPP wave-min extractions per merge).  The sort in front (rank = number of greater keys, keys are
+// unique) costs ~7 instructions per leaf.
+template <int NR>
+__device__ __forceinline__ void sorted_merge_phase(TreeLds& t, uint32_t (&kreg)[5], uint32_t& n, uint32_t& node) {
     const uint32_t l = lane_id();
-    uint32_t kreg[NREG];
+    while (n > 64u * (NR - 1) && n >= 2u) {
+        const uint32_t e1 = n - 1u, e2 = n - 2u;
+        uint32_t m1 = 0, m2 = 0;
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) kreg[r] = t.key[r * 64 + l];
-    for (uint32_t it = 0; it + 1 < S; ++it) {
-        uint32_t m = kreg[0];
+        for (int r = 0; r < NR; ++r) {  // (wave-uniform selects: the two smallest sit in the last one or two live registers)
+            if ((e1 >> 6) == (uint32_t)r) m1 = read_lane(kreg[r], e1 & 63u);
+            if ((e2 >> 6) == (uint32_t)r) m2 = read_lane(kreg[r], e2 & 63u);
+        }
+        const uint32_t nk = (((m1 >> 10) + (m2 >> 10)) << 10) | (1023u - node);
+        // insert nk among elements 0 .. n-3, from the top register down (a register's lane 0 looks at the OLD lane 63 below it)
 #pragma unroll
-        for (int r = 1; r < NREG; ++r) m = min(m, kreg[r]);
-        const uint32_t m1 = wave_min_u32(m);
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m1 ? kKeyMax : kreg[r];
-        m = kreg[0];
-#pragma unroll
-        for (int r = 1; r < NREG; ++r) m = min(m, kreg[r]);
-        const uint32_t m2 = wave_min_u32(m);
-        const uint32_t n = S + it;
-        const uint32_t nk = (((m1 >> 10) + (m2 >> 10)) << 10) | (1023u - n);
-#pragma unroll
-        for (int r = 0; r < NREG; ++r) kreg[r] = kreg[r] == m2 ? nk : kreg[r];
+        for (int r = NR - 1; r >= 0; --r) {
+            const uint32_t below = r ? read_lane(kreg[r ? r - 1 : 0], 63u) : kKeyMax;
+            const uint32_t prev = dpp<0x138>(below, kreg[r]);  // wave_shr:1 -- lane l sees lane l-1, lane 0 keeps `below`
+            kreg[r] = kreg[r] > nk ? kreg[r] : (prev > nk ? nk : prev);
+        }
         const uint32_t i1 = 1023u - (m1 & 1023u), i2 = 1023u - (m2 & 1023u);
         if (l == 0) {
-            t.up[i1] = n;                             // child_a: code bit 0, described right after the branch bit
-            t.up[i2] = n | (1u << 10) | (i1 << 11);  // child_b: code bit 1, described after child_a's subtree
+            t.up[i1] = node;                             // child_a: code bit 0, described right after the branch bit
+            t.up[i2] = node | (1u << 10) | (i1 << 11);  // child_b: code bit 1, described after child_a's subtree
         }
+        ++node;
+        --n;
     }
+}
+
+__device__ __forceinline__ void sorted_merge(TreeLds& t, uint32_t S) {
+    const uint32_t l = lane_id();
+    const uint32_t nreg = (S + 63u) >> 6;
+    // ---- sort: every key's rank = the number of keys greater than it (unique keys: a permutation) ----
+    uint32_t mine[5], rank[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        mine[r] = (uint32_t)r < nreg ? t.key[r * 64 + l] : 0u;  // (slots past S hold kKeyMax: they rank first and are written past S... see below)
+        rank[r] = 0;
+    }
+    auto count_greater = [&](uint32_t nr) {
+        for (uint32_t j = 0; j < S; ++j) {
+            const uint32_t kj = t.key[j];  // (one address for all lanes: a broadcast read)
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                if ((uint32_t)r < nr) rank[r] += kj > mine[r] ? 1u : 0u;
+        }
+    };
+    if (nreg <= 1) count_greater(1);
+    else if (nreg <= 2) count_greater(2);
+    else if (nreg <= 3) count_greater(3);
+    else count_greater(5);
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();  // (every lane has read all the keys: they are sorted in place)
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+        if ((uint32_t)r < nreg && (uint32_t)(r * 64) + l < S) t.key[rank[r]] = mine[r];
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    uint32_t kreg[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) kreg[r] = ((uint32_t)(r * 64) + l < S) ? t.key[r * 64 + l] : 0u;
+    // ---- merges, with as many registers as still hold live keys ----
+    uint32_t n = S, node = S;
+    if (nreg > 4) sorted_merge_phase<5>(t, kreg, n, node);
+    if (nreg > 3) sorted_merge_phase<4>(t, kreg, n, node);
+    if (nreg > 2) sorted_merge_phase<3>(t, kreg, n, node);
+    if (nreg > 1) sorted_merge_phase<2>(t, kreg, n, node);
+    sorted_merge_phase<1>(t, kreg, n, node);
 }
 
 struct TreeOut {  // wave-uniform
@@ -252,15 +299,13 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t nnodes = 2 * S - 1;
-    const uint32_t nreg = (S + 63) >> 6;
-    if (nreg <= 1)
-        merge_loop<1>(t, S);
-    else if (nreg <= 2)
-        merge_loop<2>(t, S);
-    else if (nreg <= 3)
-        merge_loop<3>(t, S);
-    else
-        merge_loop<5>(t, S);
+#if defined(TREE_PROBE) && TREE_PROBE == 2  // timing probes (never in the product)
+    return TreeOut{kModeFill, 1u, 0u, 0u, 0u};
+#endif
+    sorted_merge(t, S);
+#if defined(TREE_PROBE) && TREE_PROBE == 1
+    return TreeOut{kModeFill, 1u, 0u, 0u, 0u};
+#endif
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
 
