@@ -125,6 +125,20 @@ def cpu_info():
     return model, len(phys) or (os.cpu_count() or 1), os.cpu_count() or 1, usable
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), or None when unlimited: a box may show 256 logical
+    CPUs and grant 16 -- 128 workers then share 16 cores' time and the "all cores" figure is a tenth of what the cores can do"""
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q not in ("max", "-1") and int(per) > 0 and int(q) > 0:
+                return max(1, int(q) // int(per))
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def _cpu_worker(job):
     """one PROCESS of the all-cores leg: its own address space (the reference allocates a verify buffer of the block's size in
     every compress() call, signal_packer_xdelta_hzr.cpp:59 -- threads of one process serialise on that mmap/page-fault traffic)"""
@@ -157,7 +171,8 @@ def cpu_baseline(args, sample_native):
     kind = "reference" if orc_mod.have_ref() else "port"
     lib = orc_mod.Ref() if kind == "reference" else orc_mod.Oracle()
     model, physical, logical, usable = cpu_info()
-    nproc = max(1, min(usable, physical))  # every physical core this process may run on
+    quota = cpu_quota()
+    nproc = max(1, min(usable, physical, quota or physical))  # every physical core this process may run on AND has the time for
     samples_per_block = args.nch * args.ns
     # 1 core
     pk = lib.packer(args.packer, args.bps, args.nch, args.ns, args.nb)
@@ -186,9 +201,9 @@ def cpu_baseline(args, sample_native):
         "kind": kind,
         "value_1core": round(v1, 2),
         "scaling_efficiency": round(vn / (v1 * nproc), 3),
-        "parallel": "one process per physical core, one packer instance each",
+        "parallel": "one process per core the container has time for (min of physical cores, affinity, cgroup quota), one packer instance each",
         "cpu_model": model,
-        "cpus": {"physical": physical, "logical": logical, "usable": usable},
+        "cpus": {"physical": physical, "logical": logical, "usable": usable, "cgroup_quota": quota},
         "sample": "%d + %d compress() calls of one %dch x %d x int%d synthetic block (%s), verify-decode included as in the reference"
         % (n1, calls, args.nch, args.ns, 8 * args.bps, args.packer),
     }

@@ -893,6 +893,11 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
         uint32_t* queue = L < kLightPayload ? d.stage + kTokQueueBase + w * kQueueEntries : nullptr;
 #pragma unroll 1
         for (int r = 0; r < 4; ++r) {
+#if defined(ENC_PROBE) && ENC_PROBE == 2  // no emit at all
+            if (true) {
+                asm volatile("" ::"v"(W[0][0] ^ W[0][1] ^ W[0][2] ^ W[0][3]));
+            } else
+#endif
             if (row_is_dense(W[0], rc[0]))
                 emit_row_dense(W[0], rc[0], d.tab, d.runcls, d.stage, base);
             else
@@ -935,7 +940,11 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             return d.crc[0][c & 0xFFu] ^ d.crc[1][(c >> 8) & 0xFFu] ^ d.crc[2][(c >> 16) & 0xFFu] ^ d.crc[3][c >> 24];
         };
         uint32_t c = 0;
+#if defined(ENC_PROBE) && ENC_PROBE == 1  // timing probes (never in the product): no CRC
+        if (false) {
+#else
         if (tid < nvw) {
+#endif
             int32_t a = (Lv >> 2) - 1 - (int32_t)(tid + kEncThreads * (K - 1u));
             if (K > 1u) {
                 c = a >= -1 ? vword(max(a, -1)) : 0u;  // (the top word: there for the low lanes only)
@@ -984,7 +993,9 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
     if (tid < tail) po[head + 4 * nd + tid] = (uint8_t)stage_byte(d.stage, 4 + head + 4 * nd + tid);
     uint32_t* pw = reinterpret_cast<uint32_t*>(po + head);
     // payload bytes [head+4i, head+4i+4) = image bytes from 4+head+4i: off the LDS word grid by (head & 3)
+#if !(defined(ENC_PROBE) && ENC_PROBE == 3)  // no copy-out
     for (uint32_t i = tid; i < nd; i += kEncThreads) pw[i] = __builtin_amdgcn_alignbyte(d.stage[i + 2], d.stage[i + 1], head);
+#endif
     ENC_STAMP(5);
 #ifdef RSPT_DIAG
     if (stamps && threadIdx.x == 0 && list_pos < 6000u) stamps[list_pos * 16u + 6u] = ((unsigned long long)m.mode << 32) | L;

@@ -15,6 +15,12 @@ timeout -k 10 200 python bench.py --no-cpu --workload c5 > $O/bench_c5.json 2>> 
 timeout -k 10 200 python bench.py --no-cpu --op decompress > $O/bench_decompress.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --no-cpu --packer hadamard --blocks 16 > $O/bench_hadamard.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --no-cpu --packer dct --blocks 16 > $O/bench_dct.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --no-cpu --big-endian > $O/bench_big_endian.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --no-cpu --blocks 1 > $O/bench_one_block.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --op prefilter --steps 5 --warmup 1 > $O/bench_prefilter.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --op prefilter --iir-mode shared --steps 2 --warmup 1 > $O/bench_prefilter_shared.json 2>> $O/bench.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -- python3 bench.py --steps 20 --warmup 2 --no-cpu --no-verify --op decompress > $O/dstats.log 2>&1
+find $O/dstats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/dec_kernel_stats.csv; rm -rf $O/dstats
 timeout -k 10 100 python tools/host_api_rate.py > $O/host_api_rate.txt 2>> $O/bench.err
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 find $O -name "*.db" -delete; find $O -name "*_agent_info.csv" -delete
