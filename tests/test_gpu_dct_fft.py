@@ -110,8 +110,9 @@ def test_dct_large_ns(api, orc, bps, nch, ns, nblocks):
 
 
 def test_dct_16384_against_the_reference_stream(api, orc, golden):
-    """The FFT path held to the REAL reference (fixture generated from oracle/_ref at ns = 16384, the largest shape the
-    reference runs in seconds): CR / PRDN gate of SURVEY 8d, coefficients equal except truncation-boundary flips of 1."""
+    """The FFT path held to the REAL reference (fixtures generated from oracle/_ref at ns = 16384 and at ns = 32768, the
+    reference's own limit -- one octave below BASELINE config 4): CR / PRDN gate of SURVEY 8d, coefficients equal except
+    truncation-boundary flips of 1."""
     import cases
 
     for c in cases.dct_big_cases():
