@@ -88,15 +88,19 @@ constexpr uint32_t kSegHistStride = kEncWaves * kSymStride;  // u16 elements per
 constexpr int kTreeWaves = 4;
 constexpr uint32_t kKeyMax = 0xFFFFFFFFu;
 
+// (5084 bytes per tree: eight 4-wave workgroups = 32 trees in flight per CU.  The kernel is a latency chain per wave -- one dense
+//  tree alone takes 0.045 ms -- so trees in flight are what it lives on: at 6.4 KB per tree a CU held 24.)
 struct TreeLds {
-    uint32_t key[5 * 64];         // leaf keys: count<<10 | (1023 - index); index order = creation order
+    uint32_t key[kSymStride];     // leaf keys: count<<10 | (1023 - index); index order = creation order
     uint32_t lcnt[kNumSym];       // leaves in the subtree of each node, two u16 counts per word (LDS per wave decides how many
                                   // trees a CU builds at once, and the merge loop is a chain of dependent reductions)
-    uint32_t up[2 * kNumSym];     // parent | isB<<10 | sibling<<11 (sibling = child_a, kept for child_b only)
+    uint32_t up[2 * kNumSym];     // parent | isB<<10 | sibling<<11 (sibling = child_a, kept for child_b only).  Until the merges start
+                                  // its first 264 words hold the block's token histogram (lhist(): dead once the counts are in registers)
     uint16_t leafsym[kSymStride];
     uint32_t tdesc[kTdescWords];
-    uint32_t lhist[kSymStride];  // token histogram of this wave's block
+    __device__ __forceinline__ uint32_t* lhist() { return up; }
 };
+static_assert(sizeof(TreeLds) * 4 * 8 <= 160 * 1024, "eight k_tree workgroups per CU");
 
 // add the tokens of a zero run of length R to a histogram (same split as run_bits / run_emit)
 __device__ __forceinline__ void run_count(uint32_t* h, uint32_t R) {
@@ -217,7 +221,7 @@ __device__ __forceinline__ void sorted_merge(TreeLds& t, uint32_t S) {
     uint32_t mine[5], rank[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-        mine[r] = (uint32_t)r < nreg ? t.key[r * 64 + l] : 0u;  // (slots past S hold kKeyMax: they rank first and are written past S... see below)
+        mine[r] = (uint32_t)(r * 64) + l < S ? t.key[r * 64 + l] : kKeyMax;  // (lanes past the last leaf take no part)
         rank[r] = 0;
     }
     auto count_greater = [&](uint32_t nr) {
@@ -283,7 +287,7 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
     if (zero_kind + nonzero_syms == 1) return TreeOut{kModeFill, 1u, 0u, 0u, zero_kind ? 0u : fillval};  // EncodeFill (:341-367)
 
     // ---- node arrays -------------------------------------------------------
-    for (uint32_t i = l; i < 5 * 64; i += 64) t.key[i] = kKeyMax;
+    for (uint32_t i = l; i < (uint32_t)kSymStride; i += 64) t.key[i] = kKeyMax;
     for (uint32_t i = l; i < (uint32_t)kNumSym; i += 64) t.lcnt[i] = (2u * i < S ? 1u : 0u) | (2u * i + 1u < S ? 1u << 16 : 0u);
     for (uint32_t i = l; i < (uint32_t)kTdescWords; i += 64) t.tdesc[i] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -343,7 +347,15 @@ __device__ __forceinline__ TreeOut build_tree(TreeLds& t, const uint32_t* h, uin
         const uint32_t wi = off >> 5, sh = off & 31u;
         atomicOr(&t.tdesc[wi], v << sh);
         if (sh > 22) atomicOr(&t.tdesc[wi + 1], v >> (32 - sh));
-        bits_sum += h[sym] * (len + run_extra_bits(sym));
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    // payload bits of the codes: every symbol's count (still in this lane's registers: the histogram's LDS words were taken over
+    // by the tree's links) times its stream bits per token
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t s2 = r * 64 + l;
+        if (cnt[r]) bits_sum += cnt[r] * t.key[s2 < (uint32_t)kNumSym ? s2 : 0u];
     }
     bits_sum = wave_add_u32(bits_sum);
     const uint32_t ntok = wave_add_u32(cnt[0] + cnt[1] + cnt[2] + cnt[3] + cnt[4]);
@@ -392,7 +404,7 @@ __global__ __launch_bounds__(kTreeWaves * 64) void k_tree(const uint32_t* __rest
         return;
     }
     const uint32_t in_size = min(kHzrBlock, g.N - j * kHzrBlock);
-    uint32_t* h = t.lhist;
+    uint32_t* h = t.lhist();
     const bool own_hist = (uint32_t)__popc(segmask) <= kSmallSegments;
     if (l == 0) segbase[(size_t)hb * kEncWaves] = 0xFFFFFFFFu;  // "no segment offsets" unless set below
     if (own_hist) {  // small block: this wave takes the histogram itself
