@@ -583,14 +583,15 @@ __device__ __forceinline__ uint32_t run_class_entry(uint32_t z) {
     return sym | (run_extra_bits(sym) << 12) | (base << 16);
 }
 
-// OR up to 64 bits (hi:lo) into the image at bit `pos`: three words, unconditionally (zeros are harmless and
-// with 64 lanes some lane needs each of them anyway)
-__device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi) {
+// OR a string of `len` <= 64 bits (hi:lo) into the image at bit `pos`.  Two words always; the third only where some lane's
+// string reaches into it -- with the usual four codes of ~5.5 bits per string that is no lane of the wave, and the third
+// atomic with its shifts and address is one instruction in eight of the dense emit (one wave-wide test instead)
+__device__ __forceinline__ void or_bits64(uint32_t* stage, uint32_t pos, uint32_t lo, uint32_t hi, uint32_t len) {
     const uint32_t word = pos >> 5, sh = pos & 31u;
     const uint64_t sv = (((uint64_t)hi << 32) | lo) << sh;
     atomicOr(&stage[word], (uint32_t)sv);
     atomicOr(&stage[(word + 1)], (uint32_t)(sv >> 32));
-    atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
+    if (__builtin_amdgcn_ballot_w64(sh + len > 64u)) atomicOr(&stage[(word + 2)], (hi >> 1) >> (31u - sh));
 }
 
 // OR one token (<= 38 bits) into the image at bit `pos`

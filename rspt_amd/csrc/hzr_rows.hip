@@ -299,7 +299,7 @@ __device__ __forceinline__ void emit_row_dense(const uint32_t (&w)[4], const Row
     base += read_lane(inc, 63);
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd)
-        if (qlen[qd] && !((slow >> qd) & 1u)) or_bits64(stage, pq[qd], qlo[qd], qhi[qd]);
+        if (qlen[qd] && !((slow >> qd) & 1u)) or_bits64(stage, pq[qd], qlo[qd], qhi[qd], qlen[qd]);
     if (__ballot(slow != 0)) {
         if (!anylong) v = lane_view(w, rc, M);
         const uint32_t qmask = ((slow & 1u) ? 0x000Fu : 0u) | ((slow & 2u) ? 0x00F0u : 0u) | ((slow & 4u) ? 0x0F00u : 0u) | ((slow & 8u) ? 0xF000u : 0u);
@@ -445,7 +445,7 @@ __device__ __forceinline__ void emit_entries(uint32_t R, uint32_t lit, const uin
     uint32_t pos = base + inc - len;
     base += read_lane(inc, 63);
     if (q) pos += emit_run(stage, tab, runcls, pos, q * kRunCap);
-    if (vlen) or_bits64(stage, pos, (uint32_t)V, (uint32_t)(V >> 32));
+    if (vlen) or_bits64(stage, pos, (uint32_t)V, (uint32_t)(V >> 32), vlen);
 }
 
 __device__ __forceinline__ void emit_row_sparse(const uint32_t (&w)[4], const RowCtx& rc, uint32_t in_size, const uint2* tab, const uint32_t* runcls,

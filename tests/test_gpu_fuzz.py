@@ -58,6 +58,13 @@ def _gen(seed, n, kind):
         idx2 = r.integers(0, n - 3, n // 9)
         x[idx2] = 0
         x[idx2 + 1] = 0
+    elif kind == "deep":  # Fibonacci counts: codes of up to ~21 bits in dense rows, the rarest symbols side by side (pairs of codes > 32 bits)
+        fib = [1, 1]
+        while sum(fib) + fib[-1] + fib[-2] <= n:
+            fib.append(fib[-1] + fib[-2])
+        vals = np.concatenate([np.full(c, 10 + i, dtype=np.int64) for i, c in enumerate(fib)])
+        rest = n - vals.size
+        x = np.concatenate([vals[:8], r.permutation(vals[8:]), np.full(rest, 10 + len(fib) - 1, dtype=np.int64)])  # rare ones first, in order
     else:
         raise ValueError(kind)
     return x.astype(np.uint8)
@@ -68,7 +75,7 @@ def _geom(k, q):
     return p / p.sum()
 
 
-KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos"]
+KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos", "deep"]
 SIZES = [65536, 65536 * 3 + 1234, 4097, 200000, 16, 70000]
 CASES = [(k, SIZES[(i + j) % len(SIZES)], 100 * i + j) for i, k in enumerate(KINDS) for j in range(3)]
 
