@@ -501,19 +501,24 @@ __global__ __launch_bounds__(256) void k_layout(Geom g, const uint32_t* __restri
             atomicOr(&s_dirty[k * 4 + (bucket >> 5)], 1u << (bucket & 31u));
         }
     }
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        uint64_t run = 0;
-        for (uint32_t i = 0; i < 256; ++i) {
-            uint64_t v = s_part[i];
-            s_part[i] = run;
-            run += v;
+    // exclusive prefix of the 256 partial sums: a scan inside each wave, the four wave totals through LDS (the single-thread
+    // loop over 256 LDS words this replaces was most of the kernel's 13 us: ~50 dependent LDS round trips per microsecond)
+    uint64_t run;
+    {
+        const uint32_t l = tid & 63u, wv = tid >> 6;
+        uint64_t inc = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint64_t up = (uint64_t)__shfl_up((long long)inc, dd, 64);
+            if (l >= (uint32_t)dd) inc += up;
         }
+        if (l == 63u) s_part[wv] = inc;
+        __syncthreads();
+        uint64_t pre = 0;
+        for (uint32_t q2 = 0; q2 < wv; ++q2) pre += s_part[q2];
+        run = pre + inc - sum;
     }
-    __syncthreads();
     // absolute offset of hzr block q: 1 + hdr + 8*(k+1) + sum of the encoded blocks before it
-    uint64_t run = s_part[tid];
     const uint64_t head = 1ull + g.hdr_len;
     for (uint32_t q = lo; q < hi; ++q) {
         const uint32_t k = q / g.nblk;

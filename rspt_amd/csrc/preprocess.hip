@@ -275,6 +275,7 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t tid = threadIdx.x, nthr = blockDim.x;
     const bool fixup = nbuse != nullptr;
+    if (fixup && *nb_state <= kfirst) return;  // (no block of the batch needs more planes than the main pass wrote)
     const uint32_t tiles_per_block = (g.ns + T - 1) / T;
     // persistent: the grid is a few workgroups per CU, each walks tiles with a fixed stride
     const uint32_t total = tiles_per_block * nblocks;
@@ -529,6 +530,10 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     constexpr int kAhead = 2 * (XDELTA ? 18 : 16);  // hand-issued loads of the two younger sets
     const uint32_t tid = threadIdx.x;
     const bool fixup = nbuse != nullptr;
+    // the fix-up pass is launched blind (the host does not know whether nb escalated in this call): the escalation scan of the main
+    // pass has left the batch's final nb in nb_state -- nothing beyond the planes already written is needed: leave at once
+    // (instead of every workgroup walking its tiles' nbuse entries: ~4 us per call for nothing)
+    if (fixup && *nb_state <= kfirst) return;
     const uint32_t tiles_per_block = (g.ns + T - 1) / T;
     const uint32_t total = tiles_per_block * nblocks;
     const uint32_t m_nch = magic_of(g.nch);
