@@ -135,13 +135,19 @@ constexpr uint32_t kDecMinChunkBits = 256;
 constexpr uint32_t kSerialTreePayload = 4096;  // bytes: below it the tree is recovered by one wave (dec_block)
 
 constexpr uint32_t kNodeSlots = 528;
+// Codes longer than the table index.  On the dense plane 0.7 % of the tokens are (11 .. 16 bits), so one lane in 64 meets one in
+// every third round of the token loops -- and the whole wave then followed it down the tree, an LDS round trip per level.  The
+// prefixes that lead to such codes are few (a handful of 1024): each of the first 32 gets a 32-entry table over the next 5 bits,
+// which ends codes up to 15 bits with ONE more read; what is deeper still (or past the 32nd prefix) walks on from there.
+constexpr uint32_t kSubBits = 5, kSubSlots = 32;
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
     uint32_t lut[1u << kLutBits];        // code of <= 10 bits: tok_meta(sym) | len<<9;  longer: kLutLong | node reached after 10 bits
     uint32_t cend[kDecThreads];          // first code boundary past a chunk's end  (lut + cend: 8 KiB of scratch for the tree parse)
     uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
-    uint32_t leaf_code[kSymStride];
-    uint16_t leaf_meta[kSymStride];  // sym | len<<9
+    uint32_t lut2[kSubSlots << kSubBits];  // second level: slot s covers the 5 bits behind a 10-bit prefix that is no code yet
+    uint32_t slot_node[kSubSlots];         // the node such a prefix leads to
+    uint32_t nslot;                        // prefixes that asked for a slot (the first kSubSlots got one)
     uint32_t wsum[kDecThreads / 64];
     uint32_t nleaf, nnode, endpos;
     uint32_t err;
@@ -149,6 +155,8 @@ struct DecLds {
     uint32_t code0;  // first bit of the codes
 };
 constexpr uint32_t kLutLong = 0x80000000u;
+constexpr uint32_t kLutSub = 0x40000000u;  // with kLutLong: the low bits are a slot of lut2, not a node
+static_assert(sizeof(DecLds) + 64 <= 80 * 1024, "two workgroups per CU");
 constexpr uint32_t kNodeLeaf = 0x80000000u;
 
 // 32 stream bits starting at absolute bit position `bp` of the LDS image
@@ -208,20 +216,27 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
             // kLutSlow: no such code (a speculative round in the middle of raw bits, or a corrupt stream).  Else a code longer
             // than the table index: walk on from the node the first 10 bits lead to (one LDS read per level), all lanes in
             // step; the others re-read a clamped slot and keep what they have
-            const bool islong = (int32_t)e < 0;
             bool bad = e == kLutSlow;
-            uint32_t nd = min(e & 1023u, kNodeSlots - 1u);
-            uint32_t wv = d.node[nd], len2 = kLutBits;
-            for (;;) {
-                const bool step = islong && !bad && !(wv & kNodeLeaf) && len2 < 32u;
-                if (!any_lane(step)) break;
-                const uint32_t nn = min(((lo >> (len2 & 31u)) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
-                nd = step ? nn : nd;
-                wv = d.node[nd];
-                len2 += step ? 1u : 0u;
+            // second level: the next 5 bits pick the entry of the prefix's slot -- a code of 11 .. 15 bits, or the node a longer one goes on from
+            const bool sub = !bad && (e & (kLutLong | kLutSub)) == (kLutLong | kLutSub);
+            const uint32_t e2 = d.lut2[sub ? ((e & (kSubSlots - 1u)) << kSubBits) | ((lo >> kLutBits) & ((1u << kSubBits) - 1u)) : 0u];
+            e = sub ? e2 : e;
+            const bool islong = (int32_t)e < 0 && !bad;
+            if (any_lane(islong)) {
+                uint32_t nd = min(e & 1023u, kNodeSlots - 1u);
+                uint32_t wv = d.node[nd], len2 = sub ? kLutBits + kSubBits : kLutBits;
+                for (;;) {
+                    const bool step = islong && !(wv & kNodeLeaf) && len2 < 32u;
+                    if (!any_lane(step)) break;
+                    const uint32_t nn = min(((lo >> (len2 & 31u)) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
+                    nd = step ? nn : nd;
+                    wv = d.node[nd];
+                    len2 += step ? 1u : 0u;
+                }
+                bad = bad || (islong && !(wv & kNodeLeaf));
+                e = islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
             }
-            bad = bad || (islong && !(wv & kNodeLeaf));
-            e = bad ? 0u : islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
+            e = bad ? 0u : e;
             lim = bad ? 0u : lim;
             err |= bad ? 1u : 0u;
         }
@@ -261,6 +276,14 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
     return bp;
 }
 
+// table entry of a 10-bit prefix that ends at branch `nd`: a slot of the second level while there are any
+__device__ __forceinline__ uint32_t long_prefix_entry(DecLds& d, uint32_t nd) {
+    const uint32_t sl = atomicAdd(&d.nslot, 1u);
+    if (sl >= kSubSlots) return kLutLong | nd;
+    d.slot_node[sl] = nd;
+    return kLutLong | kLutSub | sl;
+}
+
 __shared__ DecLds g_dec;
 
 // one hzr block (plane k, block j of stream b) by one 1024-thread workgroup
@@ -298,6 +321,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     for (uint32_t o = tid * 16; o < skew + L; o += kDecThreads * 16)
         *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
     if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // the bit window reads up to two words past the last payload word
+    if (tid == 0) d.nslot = 0;
     __syncthreads();
 
     if (vcc) {
@@ -458,7 +482,9 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
                 ++len;
             }
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
-            d.lut[e] = (wv & kNodeLeaf) ? (tok_meta(wv & 511u) | ((len ? len : 1u) << 9)) : (kLutLong | nd);  // longer codes continue from nd
+            uint32_t ent = tok_meta(wv & 511u) | ((len ? len : 1u) << 9);
+            if (!(wv & kNodeLeaf)) ent = long_prefix_entry(d, nd);  // longer codes continue from nd
+            d.lut[e] = ent;
         }
     }
     __syncthreads();
@@ -525,8 +551,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     //  read its marks, which the barrier above guarantees)
     uint16_t* t_open = reinterpret_cast<uint16_t*>(d.cend);  // [kNodeSlots]  subtrees still open after the node
     uint16_t* t_par = t_open + kNodeSlots;                     // parent | child_b? << 15
-    uint16_t* t_ord = t_par + kNodeSlots;                      // leaf ordinal
-    static_assert(3 * kNodeSlots * sizeof(uint16_t) <= sizeof(d.cend), "tree scratch does not fit");
+    static_assert(2 * kNodeSlots * sizeof(uint16_t) <= sizeof(d.cend), "tree scratch does not fit");
     uint32_t my_err = 0;
 #pragma unroll
     for (uint32_t q = 0; q < 3; ++q) {
@@ -554,7 +579,6 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
             if (pp <= endpos && id < kNodeSlots) {
                 const uint32_t lv = leaves_before + isleaf[q];
                 t_open[id] = (uint16_t)(1u + (id + 1u - lv) - lv);
-                t_ord[id] = (uint16_t)leaves_before;
                 if (isleaf[q] && (d.node[id] & 511u) > 260u) my_err = 1;
                 if (pp == endpos) {
                     d.nnode = id + 1;
@@ -634,21 +658,33 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
         const uint32_t w_node = d.node[i];
         if (w_node & kNodeLeaf) {
             if (depth > 31) deep = 1;
-            const uint32_t q = t_ord[i];
-            d.leaf_code[q] = code;
-            d.leaf_meta[q] = (uint16_t)((w_node & 511u) | (depth << 9));
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
             const uint32_t elen = depth ? depth : 1u;
             if (elen <= kLutBits)  // every leaf of <= 10 bits owns the entries code + m * 2^len
                 for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = tok_meta(w_node & 511u) | (elen << 9);
         } else if (depth == kLutBits) {
-            d.lut[code] = kLutLong | i;  // codes longer than the table index continue from here
+            d.lut[code] = long_prefix_entry(d, i);  // codes longer than the table index continue from here
         }
     }
     if (__syncthreads_or((int)deep)) {  // deeper than the reference's decoder supports (hzr_decode.c: 32-bit codes)
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
+    }
+    {  // second-level tables (the barrier behind either tree recovery has published the slots): thread = slot * 32 + the next 5 bits
+        const uint32_t sl = tid >> kSubBits, nsl = min(d.nslot, kSubSlots);
+        if (nsl) {  // (block-uniform)
+            if (sl < nsl) {
+                uint32_t nd = min(d.slot_node[sl], kNodeSlots - 1u), len = 0, wv = d.node[nd];
+                while (!(wv & kNodeLeaf) && len < kSubBits) {
+                    nd = min(((tid >> len) & 1u) ? wv : nd + 1u, kNodeSlots - 1u);
+                    wv = d.node[nd];
+                    ++len;
+                }
+                d.lut2[tid] = (wv & kNodeLeaf) ? (tok_meta(wv & 511u) | ((kLutBits + len) << 9)) : (kLutLong | nd);
+            }
+            __syncthreads();
+        }
     }
     const uint32_t code0 = d.code0;
     DEC_STAMP(2);
