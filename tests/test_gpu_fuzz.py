@@ -65,6 +65,12 @@ def _gen(seed, n, kind):
         vals = np.concatenate([np.full(c, 10 + i, dtype=np.int64) for i, c in enumerate(fib)])
         rest = n - vals.size
         x = np.concatenate([vals[:8], r.permutation(vals[8:]), np.full(rest, 10 + len(fib) - 1, dtype=np.int64)])  # rare ones first, in order
+    elif kind == "wide":  # five heavy symbols over 250 equally rare ones: ~100 ten-bit prefixes lead to longer codes (the decoder's
+        # second-level table has 32 slots: the rest walk the tree) -- and the payload is long enough for the parallel tree recovery
+        x = r.choice(np.arange(5, 255), size=n)
+        u = r.random(n)
+        for v, q in ((4, 0.92), (3, 0.84), (2, 0.72), (1, 0.52), (0, 0.28)):
+            x[u < q] = v
     else:
         raise ValueError(kind)
     return x.astype(np.uint8)
@@ -75,7 +81,7 @@ def _geom(k, q):
     return p / p.sum()
 
 
-KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos", "deep"]
+KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos", "deep", "wide"]
 SIZES = [65536, 65536 * 3 + 1234, 4097, 200000, 16, 70000]
 CASES = [(k, SIZES[(i + j) % len(SIZES)], 100 * i + j) for i, k in enumerate(KINDS) for j in range(3)]
 
