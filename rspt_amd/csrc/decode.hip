@@ -792,14 +792,25 @@ __device__ __forceinline__ void load_v16(const uint8_t* planes, const Geom& g, u
         pw[k][2] = w.z;
         pw[k][3] = w.w;
     }
-    const uint32_t sh = 32 - 8 * nb;
+    // 4 x 4 byte transposes (the mirror image of the front end's: preprocess.hip, transform_item): two v_perm per sample, then
+    // the sign of an nb-byte value (planes >= nb were loaded as zero)
 #pragma unroll
-    for (uint32_t e = 0; e < 16; ++e) {
-        const uint32_t s8 = (e & 3) * 8;
-        uint32_t x = ((pw[0][e >> 2] >> s8) & 0xFFu) | (((pw[1][e >> 2] >> s8) & 0xFFu) << 8) | (((pw[2][e >> 2] >> s8) & 0xFFu) << 16) |
-                     (((pw[3][e >> 2] >> s8) & 0xFFu) << 24);
-        x = nb < 4 ? (uint32_t)((int32_t)(x << sh) >> sh) : x;
-        v[e] = e < cnt ? x : 0u;
+    for (uint32_t q = 0; q < 4; ++q) {
+        const uint32_t t01 = __builtin_amdgcn_perm(pw[1][q], pw[0][q], 0x05010400u), u01 = __builtin_amdgcn_perm(pw[1][q], pw[0][q], 0x07030602u);
+        const uint32_t t23 = __builtin_amdgcn_perm(pw[3][q], pw[2][q], 0x05010400u), u23 = __builtin_amdgcn_perm(pw[3][q], pw[2][q], 0x07030602u);
+        v[4 * q] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);
+        v[4 * q + 1] = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
+        v[4 * q + 2] = __builtin_amdgcn_perm(u23, u01, 0x05040100u);
+        v[4 * q + 3] = __builtin_amdgcn_perm(u23, u01, 0x07060302u);
+    }
+    if (nb < 4) {  // (uniform)
+        const uint32_t width = 8 * nb;
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) v[e] = (uint32_t)__builtin_amdgcn_sbfe((int32_t)v[e], 0, width);
+    }
+    if (cnt < 16) {
+#pragma unroll
+        for (uint32_t e = 0; e < 16; ++e) v[e] = e < cnt ? v[e] : 0u;
     }
 }
 
