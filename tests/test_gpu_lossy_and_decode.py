@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import cases
-from streamtools import describe_mismatch
+from streamtools import describe_mismatch, parse_stream
 
 pytestmark = pytest.mark.gpu
 
@@ -132,6 +132,38 @@ def test_bit_flips_never_take_the_decoder_down(api, orc, packer_cases):
     assert reported >= 40  # (nearly every bit of a stream matters)
     dec, used = pk.decompress(s)
     assert used == len(s) and dec == c["data"].tobytes()
+    pk.close()
+
+
+@pytest.mark.parametrize("n", [65536, 3000])
+def test_tree_description_flips_with_long_codes(api, orc, n):
+    """Flips inside the tree description of a block with ~100 prefixes that lead to codes longer than the decoder's table index
+    (second-level slots, overflow walks; n = 65536: the parallel tree recovery, 3000: the one-wave parse).  Without block
+    verification a damaged tree may decode to other bytes -- what is required is that every call returns (an error or n
+    bytes) and that the handle still decodes the pristine stream."""
+    from test_gpu_fuzz import _gen
+
+    data = _gen(4242, n, "wide")
+    pk = api.new_hzr(1, 1, n)
+    s = pk.compress(data, dst_max_len=pk.max_compressed_size)
+    p = parse_stream(s)
+    mode, plen, crc, off = p["planes"][0]["blocks"][0]
+    assert plen > 300  # (a Huffman block: tree description + codes)
+    rng = np.random.default_rng(n)
+    outcomes = [0, 0]
+    for bit in rng.integers(0, min(8 * plen, 2900), 64):
+        bad = bytearray(s)
+        bad[off + 7 + (int(bit) >> 3)] ^= 1 << (int(bit) & 7)
+        try:
+            dec, used = pk.decompress(bytes(bad) + bytes(64))
+            assert len(dec) == n
+            outcomes[0] += 1
+        except api.RsptHipError as e:
+            assert e.status == -6, (bit, e.status)
+            outcomes[1] += 1
+    assert outcomes[1] > 0  # (a flipped branch / leaf bit shifts the whole description: most of them cannot be a tree)
+    dec, used = pk.decompress(s)
+    assert used == len(s) and dec == data.tobytes()
     pk.close()
 
 
