@@ -294,7 +294,11 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
                                           const uint64_t* __restrict__ pidx) {
     DecLds& d = g_dec;
     if (k >= dec_nb[b]) return;
-    const uint32_t tid = threadIdx.x, l = tid & 63u, w = tid >> 6;
+    // (opaque per block: what derives from the thread index -- a few dozen LDS addresses -- is cheap to recompute; hoisted out of
+    //  the kernel's persistent loop it sits in scratch memory and comes back by loads inside the barrier-bound tree rounds)
+    uint32_t tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const uint32_t tid = tid_, l = tid & 63u, w = tid >> 6;
     const uint32_t hb = hb_index(g, b, k, j);
 #define DEC_STAMP(i) do { if (stamps && tid == 0 && hb < 512u) stamps[hb * 8u + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     DEC_STAMP(0);

@@ -167,6 +167,33 @@ def test_tree_description_flips_with_long_codes(api, orc, n):
     pk.close()
 
 
+@pytest.mark.parametrize("kind,B", [("xdelta_hzr", 64), ("hzr", 24)])
+def test_full_size_batch_round_trip(api, kind, B):
+    """The bench's decompress workload as a test: B blocks of 64ch x 65536 int32 through compress_batch and decompress_batch,
+    three times over, compared on the device.  Every persistent decoder workgroup takes dozens of hzr blocks here -- a hand-over
+    race between two of them (a missing LDS wait in front of a barrier) showed at this size only, and not in every launch."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns = 64, 65536
+    d_src = synth.synth_batch_native(B, nch, ns, device="cuda")
+    pk = api.new_xdelta_hzr(4, nch, ns, 3) if kind == "xdelta_hzr" else api.new_hzr(4, nch, ns)
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    d_dst = torch.empty((B, stride), dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(B, dtype=torch.int64, device="cuda")
+    pk.compress_batch(d_src, d_dst, d_sizes, stride)
+    for rep in range(3):
+        d_out = torch.zeros_like(d_src)
+        d_used = torch.empty(B, dtype=torch.int64, device="cuda")
+        pk.decompress_batch(d_dst, B, stride, d_out, d_used)
+        torch.cuda.synchronize()
+        assert torch.equal(d_used, d_sizes), "rep %d: consumed lengths (or error flags) differ" % rep
+        bad = (d_out.view(B, -1) != d_src.view(B, -1)).any(dim=1).nonzero().flatten().tolist()
+        assert not bad, "rep %d: streams %s decoded to other samples" % (rep, bad[:8])
+    pk.close()
+
+
 def test_batched_decompress(api, orc):
     import torch
 
