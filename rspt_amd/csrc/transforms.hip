@@ -222,11 +222,16 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
         mean = load_mean_hdr(means, g, b, c);
     }
     fwht_regs<0, 6>(v);  // bits 0, 1, 12..15
+    // (pinned: left alone the scheduler sinks the last stage's differences -- needed in the second round only -- behind the first
+    //  round's LDS reads and keeps both of their inputs instead: 64 + 64 live registers and two dozen of them in scratch memory)
+#pragma unroll
+    for (int i = 32; i < 64; ++i) asm volatile("" : "+v"(v[i]));
 
     // transpose 1: layout 1 -> layout 2
     uint32_t w[64];
     const uint32_t half = tid >> 9;  // bit 15 of the elements this thread holds in layouts 2 and 3
     const uint32_t base2 = (((tid >> 6) & 7u) << 12) | (((tid >> 2) & 15u) << 8) | (tid & 3u);
+    const uint32_t swz2 = (base2 >> 8) & 7u;  // what fwht_swz flips in bits 2..4 of this thread's layout-2 addresses
 #pragma unroll
     for (uint32_t h = 0; h < 2; ++h) {
 #pragma unroll
@@ -236,21 +241,34 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
         }
         __syncthreads();
         if (half == h) {
+            // fwht_swz(base2 | r << 2) = base2 + ((r & 7 ^ c) << 2) + (r >> 3 << 5) with c = bits 8..10 of base2: eight addresses and
+            // immediate offsets (sixty-four computed addresses are sixty-four registers the three arrays do not leave)
 #pragma unroll
-            for (uint32_t r = 0; r < 64; ++r) w[r] = sh[fwht_swz(base2 | (r << 2))];
+            for (uint32_t n = 0; n < 8; ++n) {
+                const uint32_t* pn = sh + (base2 | ((n ^ swz2) << 2));
+#pragma unroll
+                for (uint32_t m = 0; m < 8; ++m) w[8 * m + n] = pn[m << 5];
+            }
         }
         __syncthreads();
     }
     fwht_regs<0, 6>(w);  // bits 2..7
 
-    // transpose 2: layout 2 -> layout 3 (each half: written and read by the same 512 threads)
-    uint32_t u[64];
+    // transpose 2: layout 2 -> layout 3 (each half: written and read by the same 512 threads).  Read back INTO w: with an
+    // array of its own the second round's stores still need w while the first round's loads are live -- 128 registers for the
+    // compiler, which cannot know that no thread takes part in both rounds, and 22 of them went to scratch memory (104
+    // scratch instructions per thread next to 64 loads and stores of data).
+    uint32_t(&u)[64] = w;
     const uint32_t base3 = (((tid >> 6) & 7u) << 12) | ((tid & 63u) << 2);
 #pragma unroll
     for (uint32_t h = 0; h < 2; ++h) {
         if (half == h) {
 #pragma unroll
-            for (uint32_t r = 0; r < 64; ++r) sh[fwht_swz(base2 | (r << 2))] = w[r];
+            for (uint32_t n = 0; n < 8; ++n) {
+                uint32_t* pn = sh + (base2 | ((n ^ swz2) << 2));
+#pragma unroll
+                for (uint32_t m = 0; m < 8; ++m) pn[m << 5] = w[8 * m + n];
+            }
         }
         __syncthreads();
         if (half == h) {
@@ -266,6 +284,8 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
         __syncthreads();
     }
     fwht_regs<2, 6>(u);  // bits 8..11 (register-index bits 2..5; bits 0, 1 of the index are done)
+#pragma unroll
+    for (int i = 0; i < 64; ++i) asm volatile("" : "+v"(u[i]));  // (the output phase starts from 64 finished values, not in the middle of the butterflies)
 
     const uint32_t i0 = ((tid >> 6) << 12) | ((tid & 63u) << 2);  // bits 15..12 and 7..2
     uint32_t nzk[4] = {0, 0, 0, 0};
@@ -300,6 +320,7 @@ __global__ __launch_bounds__(1024) void k_fwht64k(int32_t* __restrict__ planar, 
                     nzk[kk] |= pl[kk];
                 }
             }
+            asm volatile("" ::: "memory");  // (one quad of outputs at a time: interleaved, their temporaries spill)
         }
     }
     if (PLANES) {
