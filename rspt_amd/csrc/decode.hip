@@ -242,11 +242,16 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
         }
         const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u;
         if (COUNT) {
-            const uint32_t w2 = d.stage[wi + 2];
-            const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-            const unsigned long long win = ((unsigned long long)hi << 32) | lo;
             const uint32_t zb = (e >> 19) & 511u;
-            const uint32_t extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+            // the extra bits sit in `lo` unless code + extra bits reach past 32 (a deep code in front of a long run's count): then
+            // -- rarely -- a third image word and a 64-bit shift
+            uint32_t extra = (lo >> (len & 31u)) & ((1u << eb) - 1u);
+            if (any_lane(len + eb > 32u)) {
+                const uint32_t w2 = d.stage[wi + 2];
+                const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                const unsigned long long win = ((unsigned long long)hi << 32) | lo;
+                extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+            }
             if (WRITE) {
                 // Literals gather in the aligned dword they fall into; the dword leaves once the output position has moved to
                 // another one.  Every token takes part -- a run, or the zero entry of an idle lane, just contributes a zero
@@ -741,7 +746,9 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
 #if defined(RSPT_DIAG) && defined(RSPT_DEC_NOWRITE)  // timing probe, diagnostic builds only
     if (mine && start < limit && o0 < out_size) dec_chunk<kDecCount>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
 #else
-    if (mine && start < limit && o0 < out_size) dec_chunk<kDecWrite>(d, start, limit, bit_end, p2, out, o0, out_size, e2, out_size - o0);
+    uint32_t room = out_size - o0;  // (in a register of its own: rebuilt per token from the spilled scalar otherwise)
+    asm volatile("" : "+v"(room));
+    if (mine && start < limit && o0 < out_size) dec_chunk<kDecWrite>(d, start, limit, bit_end, p2, out, o0, out_size, e2, room);
 #endif
     // sound iff no bad code was met and exactly out_size bytes came out
     const uint32_t inc2 = wave_scan_add(p2);

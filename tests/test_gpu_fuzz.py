@@ -65,6 +65,13 @@ def _gen(seed, n, kind):
         vals = np.concatenate([np.full(c, 10 + i, dtype=np.int64) for i, c in enumerate(fib)])
         rest = n - vals.size
         x = np.concatenate([vals[:8], r.permutation(vals[8:]), np.full(rest, 10 + len(fib) - 1, dtype=np.int64)])  # rare ones first, in order
+    elif kind == "deeprun":  # "deep" with one run of 300 zeros: the long-run symbol (14 extra bits) is the rarest, so its code is the
+        # deepest -- code + extra bits reach past 32 stream bits (the decoder's 64-bit window branch)
+        if n > 1000:
+            y = _gen(seed, n - 300, "deep").astype(np.int64)  # (inserted, not overwritten: the Fibonacci counts stay what they are)
+            x = np.concatenate([y[: n // 2], np.zeros(300, dtype=np.int64), y[n // 2 :]])
+        else:
+            x = _gen(seed, n, "deep").astype(np.int64)
     elif kind == "wide":  # five heavy symbols over 250 equally rare ones: ~100 ten-bit prefixes lead to longer codes (the decoder's
         # second-level table has 32 slots: the rest walk the tree) -- and the payload is long enough for the parallel tree recovery
         x = r.choice(np.arange(5, 255), size=n)
@@ -81,7 +88,7 @@ def _geom(k, q):
     return p / p.sum()
 
 
-KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos", "deep", "wide"]
+KINDS = ["dense", "peaky", "medium", "sparse", "bursty", "noise", "const", "twos", "deep", "wide", "deeprun"]
 SIZES = [65536, 65536 * 3 + 1234, 4097, 200000, 16, 70000]
 CASES = [(k, SIZES[(i + j) % len(SIZES)], 100 * i + j) for i, k in enumerate(KINDS) for j in range(3)]
 
