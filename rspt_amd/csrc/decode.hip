@@ -142,7 +142,7 @@ constexpr uint32_t kNodeSlots = 528;
 constexpr uint32_t kSubBits = 5, kSubSlots = 32;
 struct DecLds {
     uint32_t stage[kHzrBlock / 4 + 16];  // payload image; payload byte i sits at byte (skew + i)
-    uint32_t lut[1u << kLutBits];        // code of <= 10 bits: tok_meta(sym) | len<<9;  longer: kLutLong | node reached after 10 bits
+    uint32_t lut[1u << kLutBits];        // code of <= 10 bits: tok_entry(sym, len);  longer: kLutLong | (kLutSub | slot, or the node reached after 10 bits)
     uint32_t cend[kDecThreads];          // first code boundary past a chunk's end  (lut + cend: 8 KiB of scratch for the tree parse)
     uint32_t node[kNodeSlots];           // pre-order ids (<= 521 used; walks clamp the id).  leaf: kNodeLeaf | sym;  branch: id of child_b (child_a = id + 1)
     uint32_t lut2[kSubSlots << kSubBits];  // second level: slot s covers the 5 bits behind a 10-bit prefix that is no code yet
@@ -179,13 +179,18 @@ __device__ __forceinline__ void flush_edge_dword(uint8_t* out, uint32_t dw, uint
 
 // What the token loop needs to know about a symbol: literal byte (or 256 for any run) | extra bits << 15 | output bytes
 // before the extra value << 19 (1 for a literal -- symbol 0 included: one zero byte --, else the run's base length: hzr_internal.h:117-121,
-// 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14 extra bits).  A table entry adds the code length << 9.
+// 2 / 3.. / 7.. / 23.. / 279.. zeros with 0 / 2 / 4 / 8 / 14 extra bits).  A table entry adds (code length + extra bits) << 9: tok_entry.
 __device__ __forceinline__ uint32_t tok_meta(uint32_t sym) {
     const bool lit = sym < 256u;
     const uint32_t ri = sym - 256u;  // 0..4 for a run (symbols > 260 never leave the tree parse)
     const uint32_t eb = lit ? 0u : (0xE8420u >> ((ri & 7u) * 4u)) & 15u;
     const uint32_t zb = lit ? 1u : ri == 4u ? 279u : (0x17070302u >> ((ri & 3u) * 8u)) & 255u;
     return (lit ? sym : 256u) | (eb << 15) | (zb << 19);
+}
+// a table entry: tok_meta | (code length + extra bits = what the token moves the stream position by) << 9
+__device__ __forceinline__ uint32_t tok_entry(uint32_t sym, uint32_t len) {
+    const uint32_t m = tok_meta(sym);
+    return m | ((len + ((m >> 15) & 15u)) << 9);
 }
 __device__ __forceinline__ bool any_lane(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
@@ -201,11 +206,11 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
     // and leaves as one store -- its zero bytes are zero-run bytes, zero in the pre-zeroed output as well.
     const uint32_t first_dw = o0 >> 2;
     uint32_t cur_dw = first_dw, acc = 0;
-    uint32_t lim = limit;  // 0 once the lane is done for good (its byte budget is spent, or a bad code)
+    uint32_t lim = limit;  // 0 once the lane is done for good (a bad code)
+    const uint32_t o_end = WRITE ? o0 + max_out : 0u;  // WRITE: the lane's byte budget ends here (the output position only grows)
     for (;;) {
         // (limit <= bit_end: a lane that ran over the payload is past its limit too -- tested once, behind the loop)
-        if (WRITE) lim = o - o0 < max_out ? lim : 0u;
-        const bool active = bp < lim;
+        const bool active = bp < lim && (!WRITE || o < o_end);
         if (!any_lane(active)) break;
         const uint32_t wi = bp >> 5, sh = bp & 31u;
         const uint32_t w0 = d.stage[wi], w1 = d.stage[wi + 1];  // (a done lane reads inside the slack words)
@@ -234,23 +239,28 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
                     len2 += step ? 1u : 0u;
                 }
                 bad = bad || (islong && !(wv & kNodeLeaf));
-                e = islong ? (tok_meta(wv & 511u) | (len2 << 9)) : e;
+                e = islong ? tok_entry(wv & 511u, len2) : e;
             }
             e = bad ? 0u : e;
             lim = bad ? 0u : lim;
             err |= bad ? 1u : 0u;
         }
-        const uint32_t len = (e >> 9) & 63u, eb = (e >> 15) & 15u;
+        const uint32_t adv = (e >> 9) & 63u;  // code + extra bits
         if (COUNT) {
-            const uint32_t zb = (e >> 19) & 511u;
-            // the extra bits sit in `lo` unless code + extra bits reach past 32 (a deep code in front of a long run's count): then
-            // -- rarely -- a third image word and a 64-bit shift
-            uint32_t extra = (lo >> (len & 31u)) & ((1u << eb) - 1u);
-            if (any_lane(len + eb > 32u)) {
-                const uint32_t w2 = d.stage[wi + 2];
-                const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
-                const unsigned long long win = ((unsigned long long)hi << 32) | lo;
-                extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+            const uint32_t zb = (e >> 19) & 511u, eb = (e >> 15) & 15u;
+            // Extra bits: none in most rounds of a dense block (literals and short runs), so the whole wave tests for them first.
+            // They sit in `lo` unless code + extra bits reach past 32 (a deep code in front of a long run's count): then --
+            // rarely -- a third image word and a 64-bit shift.
+            uint32_t extra = 0;
+            if (any_lane(eb != 0u)) {
+                const uint32_t len = adv - eb;
+                extra = (lo >> (len & 31u)) & ((1u << eb) - 1u);
+                if (any_lane(adv > 32u)) {
+                    const uint32_t w2 = d.stage[wi + 2];
+                    const uint32_t hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+                    const unsigned long long win = ((unsigned long long)hi << 32) | lo;
+                    extra = (uint32_t)(win >> len) & ((1u << eb) - 1u);
+                }
             }
             if (WRITE) {
                 // Literals gather in the aligned dword they fall into; the dword leaves once the output position has moved to
@@ -273,7 +283,7 @@ __device__ __forceinline__ uint32_t dec_chunk(const DecLds& d, uint32_t bp, uint
             }
             o += zb + extra;
         }
-        bp += len + eb;
+        bp += adv;
     }
     if (bp > bit_end) err = 1;  // ran over the payload
     if (WRITE) flush_edge_dword(out, cur_dw, acc);
@@ -491,7 +501,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
                 ++len;
             }
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
-            uint32_t ent = tok_meta(wv & 511u) | ((len ? len : 1u) << 9);
+            uint32_t ent = tok_entry(wv & 511u, len ? len : 1u);
             if (!(wv & kNodeLeaf)) ent = long_prefix_entry(d, nd);  // longer codes continue from nd
             d.lut[e] = ent;
         }
@@ -670,7 +680,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
             // a single-leaf tree has depth 0: the stream still spends 1 bit per symbol (hzr_decode.c:290,463-470)
             const uint32_t elen = depth ? depth : 1u;
             if (elen <= kLutBits)  // every leaf of <= 10 bits owns the entries code + m * 2^len
-                for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = tok_meta(w_node & 511u) | (elen << 9);
+                for (uint32_t e = code; e < (1u << kLutBits); e += 1u << elen) d.lut[e] = tok_entry(w_node & 511u, elen);
         } else if (depth == kLutBits) {
             d.lut[code] = long_prefix_entry(d, i);  // codes longer than the table index continue from here
         }
@@ -690,7 +700,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
                     wv = d.node[nd];
                     ++len;
                 }
-                d.lut2[tid] = (wv & kNodeLeaf) ? (tok_meta(wv & 511u) | ((kLutBits + len) << 9)) : (kLutLong | nd);
+                d.lut2[tid] = (wv & kNodeLeaf) ? tok_entry(wv & 511u, kLutBits + len) : (kLutLong | nd);
             }
             __syncthreads();
         }
