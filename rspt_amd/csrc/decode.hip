@@ -148,6 +148,7 @@ struct DecLds {
     uint32_t lut2[kSubSlots << kSubBits];  // second level: slot s covers the 5 bits behind a 10-bit prefix that is no code yet
     uint32_t slot_node[kSubSlots];         // the node such a prefix leads to
     uint32_t nslot;                        // prefixes that asked for a slot (the first kSubSlots got one)
+    uint32_t flag[4];                      // workgroup-wide "did any thread ..." answers (wg_any), zeroed with the staging
     uint32_t wsum[kDecThreads / 64];
     uint32_t nleaf, nnode, endpos;
     uint32_t err;
@@ -299,6 +300,15 @@ __device__ __forceinline__ uint32_t long_prefix_entry(DecLds& d, uint32_t nd) {
     return kLutLong | kLutSub | sl;
 }
 
+// Did any thread of the workgroup see `p`?  One barrier; slot `i` is zero when the block starts and used once per block.
+// (__syncthreads_or costs three barriers and a cross-lane reduction -- and its one-wave shortcut, never taken here, is a path on
+//  which tools/check_barrier_waits.py cannot see the LDS stores in front of it published.)
+__device__ __forceinline__ bool wg_any(DecLds& d, uint32_t i, bool p) {
+    if (p) d.flag[i] = 1u;
+    __syncthreads();
+    return d.flag[i] != 0u;
+}
+
 __shared__ DecLds g_dec;
 
 // one hzr block (plane k, block j of stream b) by one 1024-thread workgroup
@@ -341,6 +351,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
         *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(d.stage) + o) = *reinterpret_cast<const uint4*>(abase + o);
     if (tid < 4) d.stage[((skew + L + 3) >> 2) + tid] = 0;  // the bit window reads up to two words past the last payload word
     if (tid == 0) d.nslot = 0;
+    if (tid < 4) d.flag[tid] = 0;
     __syncthreads();
 
     if (vcc) {
@@ -383,7 +394,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
             for (uint32_t q = 0; q < dbytes; ++q) init = vcc->table[0][init & 0xFFu] ^ (init >> 8);
             bad_crc = (~(raw ^ init)) != ld_le32(s + 2) ? 1u : 0u;
         }
-        if (__syncthreads_or((int)bad_crc)) {
+        if (wg_any(d, 0, bad_crc != 0)) {
             if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
             return;
         }
@@ -610,7 +621,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     }
     if (tid == 0) t_par[0] = 0;
     // no complete tree inside the payload, too many nodes, or a symbol out of range
-    if (__syncthreads_or((int)(my_err || endpos == 0xFFFFFFFFu || endpos >= P))) {
+    if (wg_any(d, 1, my_err || endpos == 0xFFFFFFFFu || endpos >= P)) {
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
@@ -685,7 +696,7 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
             d.lut[code] = long_prefix_entry(d, i);  // codes longer than the table index continue from here
         }
     }
-    if (__syncthreads_or((int)deep)) {  // deeper than the reference's decoder supports (hzr_decode.c: 32-bit codes)
+    if (wg_any(d, 2, deep != 0)) {  // deeper than the reference's decoder supports (hzr_decode.c: 32-bit codes)
         if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
         return;
     }
@@ -768,8 +779,8 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     __syncthreads();
     uint32_t total = 0;
     for (uint32_t i = 0; i < kDecThreads / 64; ++i) total += d.wsum[i];
-    const uint32_t bad = (e2 || total != out_size) ? 1u : 0u;
-    if (__syncthreads_or((int)bad) && tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+    // (a bad code is reported by the lane that met it, a wrong byte count by thread 0: both rare, no vote needed)
+    if (e2 || (tid == 0 && total != out_size)) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
     DEC_STAMP(6);
     if (stamps && tid == 0 && hb < 16384u) stamps[65536u + 2u * hb + 1u] = __builtin_amdgcn_s_memrealtime();
 #undef DEC_STAMP
