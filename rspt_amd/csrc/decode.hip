@@ -531,32 +531,40 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     // scan over the marks numbers the nodes and counts the leaves, and the subtrees still open after a node follow from the
     // two counts (1 + branches - leaves), so the first node that leaves none open ends the tree.
     constexpr uint32_t kMaxDesc = 11u * kNumSym + 16u;  // description bits (11 S - 1) and a little slack
-    uint16_t* jump = reinterpret_cast<uint16_t*>(d.lut);                    // [kMaxDesc + 1]
-    uint32_t* mark = d.lut + (kMaxDesc + 2) / 2 + 1;                        // bit per position
-    static_assert(((kMaxDesc + 2) / 2 + 1 + kMaxDesc / 32 + 2) * 4 <= sizeof(d.lut) + sizeof(d.cend), "token-cut scratch does not fit");
+    // scratch: lut, cend, node and lut2 are contiguous and free until the tree is known -- two jump arrays (a round reads one and
+    // writes the other: one barrier per round instead of two) and the marks behind them, inside lut2, which nothing else writes
+    // before the second-level tables are filled
+    constexpr uint32_t kJumpLen = (kMaxDesc + 2u + 7u) & ~7u;
+    uint16_t* jump_a = reinterpret_cast<uint16_t*>(d.lut);       // [kMaxDesc + 1]
+    uint16_t* jump_b = jump_a + kJumpLen;
+    uint32_t* mark = d.lut + kJumpLen;                            // bit per position (= behind jump_b)
+    static_assert(offsetof(DecLds, cend) == offsetof(DecLds, lut) + sizeof(d.lut) && offsetof(DecLds, node) == offsetof(DecLds, cend) + sizeof(d.cend) &&
+                      offsetof(DecLds, lut2) == offsetof(DecLds, node) + sizeof(d.node),
+                  "the token cut uses lut .. lut2 as one piece of scratch");
+    static_assert(kJumpLen * 4u + (kMaxDesc / 32u + 2u) * 4u <= sizeof(d.lut) + sizeof(d.cend) + sizeof(d.node) + sizeof(d.lut2), "token-cut scratch does not fit");
+    static_assert(kJumpLen * 4u >= sizeof(d.lut) + sizeof(d.cend) + sizeof(d.node), "the marks must lie behind the node array (written while they are read)");
     const uint32_t P = min(kMaxDesc, bit_end - bit0);
     auto dbit = [&](uint32_t p) -> uint32_t { return (d.stage[(bit0 + p) >> 5] >> ((bit0 + p) & 31u)) & 1u; };
     for (uint32_t pz = tid; pz < kMaxDesc / 32 + 2; pz += kDecThreads) mark[pz] = pz == 0 ? 1u : 0u;  // position 0 is reached
-    for (uint32_t pp = tid; pp <= P; pp += kDecThreads) jump[pp] = (uint16_t)(pp < P ? min(P, pp + (dbit(pp) ? 10u : 1u)) : P);
+    for (uint32_t pp = tid; pp <= P; pp += kDecThreads) jump_a[pp] = (uint16_t)(pp < P ? min(P, pp + (dbit(pp) ? 10u : 1u)) : P);
     if (tid == 0) {
         d.err = 0;
         d.endpos = 0xFFFFFFFFu;
     }
     __syncthreads();
+    // (a mark set in this round by somebody else may or may not be seen in it: either way only reachable positions get marked,
+    //  and what a round must see -- the marks of the rounds before -- is behind a barrier)
+#pragma unroll 2
     for (uint32_t round = 0; round < 10; ++round) {
-        uint32_t j1[3], j2[3];
+        const uint16_t* jr = (round & 1u) ? jump_b : jump_a;
+        uint16_t* jw = (round & 1u) ? jump_a : jump_b;
 #pragma unroll
         for (uint32_t q = 0; q < 3; ++q) {
             const uint32_t pp = tid + q * kDecThreads;
-            j1[q] = pp <= P ? jump[pp] : P;
-            j2[q] = jump[j1[q]];
-            if (pp < P && ((mark[pp >> 5] >> (pp & 31u)) & 1u) && j1[q] < P) atomicOr(&mark[j1[q] >> 5], 1u << (j1[q] & 31u));
-        }
-        __syncthreads();  // every jump has been read, every mark of this round is set
-#pragma unroll
-        for (uint32_t q = 0; q < 3; ++q) {
-            const uint32_t pp = tid + q * kDecThreads;
-            if (pp <= P) jump[pp] = (uint16_t)j2[q];
+            const uint32_t j1 = pp <= P ? jr[pp] : P;
+            const uint32_t j2 = jr[j1];
+            if (pp < P && ((mark[pp >> 5] >> (pp & 31u)) & 1u) && j1 < P) atomicOr(&mark[j1 >> 5], 1u << (j1 & 31u));
+            if (pp <= P) jw[pp] = (uint16_t)j2;
         }
         __syncthreads();
     }
