@@ -194,6 +194,40 @@ def test_full_size_batch_round_trip(api, kind, B):
     pk.close()
 
 
+def test_a_damaged_stream_in_a_batch_leaves_its_neighbours_alone(api):
+    """One stream of a batch with a bit flipped in the tree description of a dense block, another truncated to a few bytes: both
+    are flagged in `consumed` (bit 63), every other stream of the same launch decodes to its samples."""
+    import torch
+
+    from rspt_amd import synth
+
+    B, nch, ns = 12, 64, 65536
+    d_src = synth.synth_batch_native(B, nch, ns, device="cuda")
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    d_dst = torch.empty((B, stride), dtype=torch.uint8, device="cuda")
+    d_sizes = torch.empty(B, dtype=torch.int64, device="cuda")
+    pk.compress_batch(d_src, d_dst, d_sizes, stride)
+    torch.cuda.synchronize()
+    s3 = bytes(d_dst[3, : int(d_sizes[3])].cpu().numpy())
+    blk = parse_stream(s3)["planes"][0]["blocks"][5]  # a dense plane-0 block: (mode, payload length, crc, offset)
+    d_dst[3, blk[3] + 7 + 4] ^= 0x04  # inside its tree description
+    d_dst[8, 40:] = 0  # stream 8: framing gone after 40 bytes
+    d_out = torch.zeros_like(d_src)
+    d_used = torch.empty(B, dtype=torch.int64, device="cuda")
+    pk.decompress_batch(d_dst, B, stride, d_out, d_used)
+    torch.cuda.synchronize()
+    used = d_used.cpu().numpy().astype(np.uint64)
+    flagged = [int(i) for i in range(B) if int(used[i]) >> 63]
+    assert 8 in flagged and set(flagged) <= {3, 8}, flagged  # (a flipped description bit nearly always breaks the tree; if it does not, the CRC-less decode may pass)
+    for i in range(B):
+        if i in (3, 8):
+            continue
+        assert int(used[i]) == int(d_sizes[i])
+        assert torch.equal(d_out[i], d_src[i]), i
+    pk.close()
+
+
 def test_batched_decompress(api, orc):
     import torch
 
