@@ -1173,7 +1173,14 @@ __global__ __launch_bounds__(1024) void k_inv_native(const uint8_t* __restrict__
     for (uint32_t u = tid; u < total; u += 1024u) {
         const uint32_t t = u / cpr, c4 = u - t * cpr;
         const uint32_t* r = tile + (4u * c4) * ROW + inv_col(t);
-        *reinterpret_cast<uint4*>(o + ((size_t)(s0 + t) * g.nch + cg0 + 4u * c4) * 4u) = make_uint4(r[0], r[ROW], r[2 * ROW], r[3 * ROW]);
+        uint32_t x0 = r[0], x1 = r[ROW], x2 = r[2 * ROW], x3 = r[3 * ROW];
+        if (g.be) {  // big-endian samples out (rspt_hip_set_byte_order): one v_perm per sample here instead of a pass of its own over the block
+            x0 = __builtin_amdgcn_perm(x0, x0, 0x00010203u);
+            x1 = __builtin_amdgcn_perm(x1, x1, 0x00010203u);
+            x2 = __builtin_amdgcn_perm(x2, x2, 0x00010203u);
+            x3 = __builtin_amdgcn_perm(x3, x3, 0x00010203u);
+        }
+        *reinterpret_cast<uint4*>(o + ((size_t)(s0 + t) * g.nch + cg0 + 4u * c4) * 4u) = make_uint4(x0, x1, x2, x3);
     }
 }
 

@@ -1541,7 +1541,7 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
                 else
                     launch_inv_native<false, 64>(p, B, nrow, d_dst, st);
             }
-            if (p->big_endian) launch_byteswap(p, (const uint8_t*)d_dst, (uint8_t*)d_dst, nblocks, st);
+            // (big-endian samples: k_inv_native reverses each sample as it writes it -- g.be)
             HIPCHK(p, hipGetLastError());
             return RSPT_HIP_OK;
         }

@@ -16,6 +16,7 @@ timeout -k 10 200 python bench.py --no-cpu --op decompress > $O/bench_decompress
 timeout -k 10 200 python bench.py --no-cpu --packer hadamard --blocks 16 > $O/bench_hadamard.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --no-cpu --packer dct --blocks 16 > $O/bench_dct.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --no-cpu --big-endian > $O/bench_big_endian.json 2>> $O/bench.err
+timeout -k 10 200 python bench.py --no-cpu --op decompress --big-endian > $O/bench_decompress_big_endian.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --no-cpu --blocks 1 > $O/bench_one_block.json 2>> $O/bench.err
 timeout -k 10 200 python bench.py --op prefilter --steps 5 --warmup 1 > $O/bench_prefilter.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --op prefilter --iir-mode shared --steps 2 --warmup 1 > $O/bench_prefilter_shared.json 2>> $O/bench.err
