@@ -1203,7 +1203,8 @@ __global__ __launch_bounds__(256) void k_planar_native(const int32_t* __restrict
     const bool al4 = (BPS == 4) && ((reinterpret_cast<uintptr_t>(o) & 3u) == 0);
     for (uint32_t q = tid; q < total; q += 256) {
         const uint32_t t = q / g.nch, c = q - t * g.nch;
-        const uint32_t v = (uint32_t)tile[c * RS + t];
+        uint32_t v = (uint32_t)tile[c * RS + t];
+        if (BPS > 1 && g.be) v = __builtin_amdgcn_perm(v, v, 0x00010203u) >> (8 * (4 - BPS));  // big-endian samples out: the low BPS bytes reversed
         uint8_t* p = o + (size_t)q * BPS;
         if (al4) {
             *reinterpret_cast<uint32_t*>(p) = v;
@@ -1250,7 +1251,14 @@ __global__ __launch_bounds__(256) void k_planar_native_i32x4(const int32_t* __re
         int4* o = reinterpret_cast<int4*>(dst + (size_t)b * g.block_bytes + (size_t)s0 * g.nch * 4u);
         for (uint32_t u = tid; u < Tn * cpr; u += 256) {
             const int32_t* r = tile + (4u * c4) * RS + t;
-            o[u] = make_int4(r[0], r[RS], r[2 * RS], r[3 * RS]);
+            uint32_t x0 = (uint32_t)r[0], x1 = (uint32_t)r[RS], x2 = (uint32_t)r[2 * RS], x3 = (uint32_t)r[3 * RS];
+            if (g.be) {  // big-endian samples out
+                x0 = __builtin_amdgcn_perm(x0, x0, 0x00010203u);
+                x1 = __builtin_amdgcn_perm(x1, x1, 0x00010203u);
+                x2 = __builtin_amdgcn_perm(x2, x2, 0x00010203u);
+                x3 = __builtin_amdgcn_perm(x3, x3, 0x00010203u);
+            }
+            o[u] = make_int4((int)x0, (int)x1, (int)x2, (int)x3);
             c4 += step_c;
             const uint32_t carry = c4 >= cpr ? 1u : 0u;
             c4 -= carry ? cpr : 0u;

@@ -942,26 +942,6 @@ __global__ __launch_bounds__(256) void k_tile_planar_i32x4(const uint8_t* __rest
 // nb bookkeeping (signal_packer_xdelta_hzr.cpp:63-69): nb used by block b =
 // max(nb carried in, need(0..b)); the last value is carried to the next call.
 // ---------------------------------------------------------------------------
-// Big-endian samples (convert_native_to_i32 / convert_i32_to_native with reverse_byte_order = true, utils.cpp:127-137,145-154,
-// 162-170 and :57-64,77-85,97-104): the bytes of every sample reversed, one thread per sample.  src == dst is allowed.
-template <int BPS>
-__global__ __launch_bounds__(256) void k_byteswap(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, uint64_t nsamples) {
-    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < nsamples; i += (uint64_t)gridDim.x * 256u) {
-        if (BPS == 4) {
-            const uint32_t v = reinterpret_cast<const uint32_t*>(src)[i];
-            reinterpret_cast<uint32_t*>(dst)[i] = __builtin_amdgcn_perm(v, v, 0x00010203u);
-        } else if (BPS == 2) {
-            const uint16_t v = reinterpret_cast<const uint16_t*>(src)[i];
-            reinterpret_cast<uint16_t*>(dst)[i] = (uint16_t)((v >> 8) | (v << 8));
-        } else {
-            const uint8_t a = src[3 * i], b = src[3 * i + 1], c = src[3 * i + 2];
-            dst[3 * i] = c;
-            dst[3 * i + 1] = b;
-            dst[3 * i + 2] = a;
-        }
-    }
-}
-
 // single workgroup; nblocks arbitrary (the xdelta / hzr front ends run the same scan in their last workgroup)
 __global__ __launch_bounds__(1024) void k_nb_scan(const uint32_t* __restrict__ needmask, uint32_t nblocks, uint32_t* __restrict__ nb_state,
                                                   uint32_t* __restrict__ nbuse, int use_mask) {

@@ -350,16 +350,6 @@ static void launch_fixup(rspt_hip_packer* p, const uint8_t* d_src, size_t nblock
     launch_planes<BPS, true>(p, d_src, nblocks, np, 4 - np, p->nbuse, st);
 }
 
-static void launch_byteswap(rspt_hip_packer* p, const uint8_t* src, uint8_t* dst, size_t nblocks, hipStream_t st) {
-    const uint64_t ns = (uint64_t)nblocks * p->g.nch * p->g.ns;
-    const unsigned grid = (unsigned)std::min<uint64_t>((ns + 255) / 256, 16384);
-    switch (p->g.bps) {
-        case 2: hipLaunchKernelGGL((k_byteswap<2>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
-        case 3: hipLaunchKernelGGL((k_byteswap<3>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
-        case 4: hipLaunchKernelGGL((k_byteswap<4>), dim3(grid), dim3(256), 0, st, src, dst, ns); break;
-        default: break;  // one byte per sample: nothing to reverse
-    }
-}
 
 template <int BPS, int NC>
 static void launch_iir(rspt_hip_packer* p, uint8_t* buf, uint32_t B, const IirCoef& c, int per_channel, hipStream_t st) {
@@ -1590,7 +1580,7 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
             case 3: hipLaunchKernelGGL((k_planar_native<3>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
             default: hipLaunchKernelGGL((k_planar_native<4>), ng, dim3(256), lds, st, final_planar, g, T, (uint8_t*)d_dst); break;
         }
-        if (p->big_endian && g.bps > 1) launch_byteswap(p, (const uint8_t*)d_dst, (uint8_t*)d_dst, nblocks, st);
+        // (big-endian samples: the kernels above reverse each sample as they write it -- g.be)
     }
     HIPCHK(p, hipGetLastError());
     return RSPT_HIP_OK;
