@@ -4,15 +4,19 @@
 //                  hzr_decode.c:626-674): plane chunk lengths, hzr block headers
 //                  -> per-block input offsets, consumed length, means header
 //   k_dec_block    one 1024-thread workgroup per hzr block (hzr_decode.c:335-567): copy / fill /
-//                  Huffman+RLE with a 10-bit LUT (the reference uses 8 bits) and a node walk for
-//                  longer codes; the code bits are decoded in up to 1024 self-synchronising chunks.
+//                  Huffman+RLE with a 10-bit LUT (the reference uses 8 bits), 32-entry second-level
+//                  tables for the prefixes of longer codes and a node walk for what is deeper still;
+//                  the code bits are decoded in up to 1024 self-synchronising chunks.
 //                  CRCs are checked only on request (rspt_hip_set_verify), as hzr_verify does;
 //                  the reference's decoder skips them too (hzr_decode.c:343).
 //   k_inv_*        planes -> int32 with sign extension from nb bytes
 //                  (signal_packer_base.cpp:121-138), then the inverse xdelta:
 //                  inclusive XOR scan, +128, inclusive sum (utils.cpp:204-236)
 //                  as a three-pass tiled scan over the flat array
+//   k_inv_rows / k_inv_scan_rows / k_inv_native   the same for int32 blocks with ns % 256 == 0: two passes over the planes, the
+//                  second one writes the interleaved samples itself
 //   k_planar_native   [nch][ns] int32 -> interleaved native (utils.cpp:51-121); k_planar_native_i32x4: the int32 fast path
+//                  (every kernel that writes samples reverses their bytes for a big-endian handle: utils.cpp:57-64,77-85,97-104)
 #include "common.hpp"
 
 namespace rspt {
