@@ -798,22 +798,23 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
 #undef DEC_STAMP
 }
 
-// Persistent grid over the hzr blocks, plane-major (the dense plane-0 blocks first): the first block of a workgroup is
-// static, the rest come from a counter.
+// Persistent grid over the hzr blocks: the first block of a workgroup is static, the rest come from a counter.  The order is
+// plane-fastest -- dense plane-0 blocks and the light ones of the planes above take turns -- so that a CU's two workgroups are
+// in different kinds of block, and in different phases, most of the time (all dense blocks first, the light ones as tail filler:
+// 1.729 ms per 64-block batch; in turns: 1.677).
 __global__ __launch_bounds__(kDecThreads, 8) void k_dec_block(const uint8_t* __restrict__ src, uint64_t src_stride, Geom g,
                                                           const uint32_t* __restrict__ dec_nb, const uint64_t* __restrict__ blk_off,
                                                           uint8_t* __restrict__ planes, uint64_t* __restrict__ consumed,
                                                           unsigned long long* __restrict__ stamps, const CrcConsts* __restrict__ vcc,
                                                           const uint64_t* __restrict__ pidx, uint32_t* __restrict__ counter, uint32_t total) {
     __shared__ uint32_t s_next;
-    const uint32_t per_plane = total / kMaxPlanes;  // blocks * nblk
     for (uint32_t pass = 0;; ++pass) {
         __syncthreads();  // everyone is done with the previous block's LDS (and with s_next)
         if (threadIdx.x == 0) s_next = pass == 0 ? blockIdx.x : gridDim.x + atomicAdd(counter, 1u);
         __syncthreads();
         const uint32_t i = s_next;
         if (i >= total) break;
-        const uint32_t k = i / per_plane, x = i - k * per_plane;
+        const uint32_t k = i % kMaxPlanes, x = i / kMaxPlanes;
         dec_block(k, x % g.nblk, x / g.nblk, src, src_stride, g, dec_nb, blk_off, planes, consumed, stamps, vcc, pidx);
     }
 }

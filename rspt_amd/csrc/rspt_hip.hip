@@ -1503,6 +1503,7 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         {
             // persistent: block costs differ 10x (dense plane 0 against light planes) and the dispatcher places workgroup i
             // on XCD i % 8 in order, so a plain grid ran its second half at a quarter of the slots (tools/census_decode.py)
+            // (k_dec_block takes the blocks plane-fastest: dense and light ones in turns)
             const uint32_t total = g.nblk * B * kMaxPlanes;
             const uint32_t want = 2u * (uint32_t)p->num_cu;  // two 1024-thread workgroups (76 KiB of LDS each) per CU
             hipLaunchKernelGGL(k_dec_block, dim3(want < total ? want : total), dim3(kDecThreads), 0, st, src, (uint64_t)src_stride, g, p->dec_nb, p->blk_off,
