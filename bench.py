@@ -368,7 +368,7 @@ def main():
     gathered_bytes = [0]
     # c5: the containers of step i leave during step i + 1 (sizes by a device all-gather, read by the host one step later: no host
     # round trip inside a step; rspt_amd/shard.py LaggedGather); the last step's payload is flushed inside the timed region
-    lag = shard.LaggedGather(dst=0, recv_bufs=recv_bufs, device=dev) if (do_gather and c5) else None
+    lag = shard.LaggedGather(dst=0, recv_bufs=recv_bufs, device=dev, timing=True) if (do_gather and c5) else None
     slot_free = [None, None]  # event: the gather that last used this slot's buffers has finished
     sizes_all = [torch.zeros((world, B), dtype=torch.int64, device=dev) for _ in range(2)] if (do_gather and not c5) else None
 
@@ -381,8 +381,12 @@ def main():
         d_back = torch.empty((B, pk.block_bytes), dtype=torch.uint8, device=dev)
         d_used = torch.empty(B, dtype=torch.int64, device=dev)
 
-    def one_step(i):
-        slot = i & 1
+    nstep = [0]  # steps so far: runs on through warm-up and timed loop, so that the buffer parity never jumps (the lagged gather's own
+    #              slot parity is a step counter too)
+
+    def one_step(_i):
+        slot = nstep[0] & 1
+        nstep[0] += 1
         if decomp:
             pk.decompress_batch(d_dst[slot], B, dst_stride, d_back, d_used)
             return
@@ -443,7 +447,7 @@ def main():
     # could take the output of only 2-3 GPUs at this rate); its time is reported beside the metric
     gather_ms = None
     if do_gather and not payload_every_step:
-        last = (args.steps - 1) & 1
+        last = (nstep[0] - 1) & 1
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
@@ -458,7 +462,7 @@ def main():
     # outside the timed region: both batches once more, their first and last streams against the oracle
     verified = None
     if decomp:  # the last decoded batch is the input again (lossless packers), and the decoder consumed every stream in full
-        last = (args.steps - 1) & 1
+        last = (nstep[0] - 1) & 1
         ok_len = bool(torch.equal(d_used, d_sizes[last]))
         decode_ok = ok_len and (bool(torch.equal(d_back.view(-1), d_src[last].view(-1))) if args.packer in ("xdelta_hzr", "hzr") else True)
     for s in range(2):

@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
                                                           const CrcConsts* __restrict__ cc, uint8_t* __restrict__ dst, uint64_t dst_stride,
                                                           WorkQueues* __restrict__ wq, const uint32_t* __restrict__ big_list,
                                                           const uint32_t* __restrict__ segbase, const uint32_t* __restrict__ lists,
-                                                          const uint2* __restrict__ listinfo, unsigned long long* __restrict__ stamps) {
+                                                          const uint2* __restrict__ listinfo, unsigned long long* __restrict__ stamps, uint32_t yield) {
     (&g_e.crc[0][0])[threadIdx.x] = (&cc->shift[78][0][0])[threadIdx.x];  // multiplication by x^(8*4096): 4 x 256 entries, once per workgroup
     if (threadIdx.x < kRunClsEntries) g_e.runcls[threadIdx.x] = run_class_entry(threadIdx.x);
     if (threadIdx.x == 0) g_e.zero_word = 0;
@@ -1017,8 +1017,9 @@ __global__ __launch_bounds__(kEncThreads, 8) void k_encode(uint8_t* __restrict__
     // wave slot of a CU, so the small ones only get in as these retire, and ran on for ~20 us behind the last big block.  When
     // there are enough small blocks for that to matter an eighth of the grid steps aside from the start: the small-block kernel
     // then ends well before this one (64-block batch: encode 0.333 + 0.021 behind it -> 0.328 + 0.010; with few small blocks
-    // the full grid is the faster one).  Every workgroup takes the same decision from the same counter.
-    const uint32_t act = wq->n_small >= kYieldSmallBlocks && gridDim.x >= 16u ? gridDim.x - gridDim.x / 8u : gridDim.x;
+    // the full grid is the faster one).  Every workgroup takes the same decision from the same counter.  `yield` = 0: the small-block
+    // kernel of this batch ran earlier, beside the next batch's front end (two batches in flight).
+    const uint32_t act = yield && wq->n_small >= kYieldSmallBlocks && gridDim.x >= 16u ? gridDim.x - gridDim.x / 8u : gridDim.x;
     if (blockIdx.x >= act) return;
     // persistent: one big block per workgroup pass; the first one is static (index = workgroup id), the
     // rest come from a counter (one shared word sustains only ~88 fetch-adds per microsecond)

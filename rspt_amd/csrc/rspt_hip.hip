@@ -201,6 +201,8 @@ struct rspt_hip_packer {
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
+    uint32_t hist_grid = 0;     // workgroups of the persistent k_hist / k_encode; 0 = two per CU (a CU's wave slots: one batch at a time)
+    uint32_t enc_grid = 0;
     uint32_t ablate = 0;  // RSPT_ABLATE (diagnostic builds only; the product kernels ignore it): timing probes
     uint32_t psel = 0;    // RSPT_PLANESEL (diagnostic builds only): which planes the hzr kernels take; bit 8 / 9: stop behind k_hist / k_tree
     int verify = 0;       // decompress checks the block CRCs (rspt_hip_set_verify)
@@ -568,6 +570,8 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
     if (const char* e = getenv("RSPT_PLANESEL")) p->psel = (uint32_t)atoi(e);
     if (const char* e = getenv("RSPT_K1_THREADS")) p->k1_threads = (uint32_t)atoi(e) / 64 * 64;
     if (const char* e = getenv("RSPT_K1_GRID")) p->k1_grid = (uint32_t)atoi(e);
+    if (const char* e = getenv("RSPT_HIST_GRID")) p->hist_grid = (uint32_t)atoi(e);
+    if (const char* e = getenv("RSPT_ENC_GRID")) p->enc_grid = (uint32_t)atoi(e);
 #endif
     if (p->k1_threads < 64 || p->k1_threads > 256) p->k1_threads = 256;  // (k_tile_planes is compiled for <= 256)
     p->ntile = (g.N + kInvTile - 1) / kInvTile;
@@ -619,19 +623,24 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
         delete p;
         return RSPT_HIP_ERR_LAUNCH;
     }
-    static CrcConsts cc;  // ~87 KB: keep it off the stack
-    make_crc_consts(cc);
     p->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, 4 * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
+    if (hipMalloc(&p->stamps, (512 * 16 * 8 + 2 * 16384) * sizeof(unsigned long long)) != hipSuccess) {
         rspt_hip_packer_destroy(p);
         return RSPT_HIP_ERR_ALLOC;
     }
-    uint32_t nb0 = p->nb_ctor;
-    if (hipMemcpy(p->crc, &cc, sizeof(cc), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(p->nb_state, &nb0, sizeof(nb0), hipMemcpyHostToDevice) != hipSuccess) {
-        rspt_hip_packer_destroy(p);
-        return RSPT_HIP_ERR_LAUNCH;
+    {
+        static CrcConsts cc;  // ~87 KB: keep it off the stack
+        make_crc_consts(cc);
+        if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, 4 * sizeof(uint32_t)) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_ALLOC;
+        }
+        uint32_t nb0 = p->nb_ctor;
+        if (hipMemcpy(p->crc, &cc, sizeof(cc), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(p->nb_state, &nb0, sizeof(nb0), hipMemcpyHostToDevice) != hipSuccess) {
+            rspt_hip_packer_destroy(p);
+            return RSPT_HIP_ERR_LAUNCH;
+        }
     }
     for (int i = 0; i <= ST_COUNT; ++i) hipEventCreate(&p->ev[i]);
     // (highest priority: the latency-bound small blocks go first and are done long before the big encoder, so that the
@@ -725,8 +734,8 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     hipSetDevice(p->device);
     if (p->stream) hipStreamSynchronize(p->stream);
     free_workspace(p);
-    hipFree(p->crc);
     hipFree(p->stamps);
+    hipFree(p->crc);
     hipFree(p->nb_state);
     hipFree(p->cos_tab);
     hipFree(p->cos_tab_t);
@@ -824,18 +833,18 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     return RSPT_HIP_OK;
 }
 
-int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nblocks, void* d_dst, size_t dst_stride, uint64_t* d_sizes,
-                                void* stream) {
-    if (!p || !d_src || !d_dst || !d_sizes || nblocks == 0) return RSPT_HIP_ERR_ARG;
-    if (reinterpret_cast<uintptr_t>(d_src) & 15) return RSPT_HIP_ERR_ARG;  // tile loads are 16-byte aligned chunks
-    int rc = rspt_hip_reserve(p, nblocks);
-    if (rc) return rc;
-    HIPCHK(p, hipSetDevice(p->device));
-    hipStream_t st = (hipStream_t)stream;
+// ---- the compress sequence, phase by phase ----------------------------------------------------------------------------------------
+// (Round 4 measured whether the phases of TWO batches can overlap -- two whole batches racing on two streams, and an ordered
+// schedule with the latency-bound middle of batch i on a second stream beside the front end of batch i+1: neither beats one
+// batch at a time on one stream; profiles/r04_notes.md, profiles/r04_pipeline_experiment.patch.)
+// front:  zero region, front-end kernel(s), escalation scan / fix-up, list of k_hist's blocks     (HBM-bound)
+// hist:   k_hist                                                                                  (vector-issue bound)
+// tree:   k_tree + k_layout                                                                       (latency chains, chip mostly idle)
+// small:  k_encode_small                                                                          (latency-bound, one wave per block)
+// encode: k_encode                                                                                (vector-issue bound)
+static int phase_front(rspt_hip_packer* p, const uint8_t* src, size_t nblocks, hipStream_t st) {
     const Geom& g = p->g;
-    const uint8_t* src = (const uint8_t*)d_src;
     const uint32_t B = (uint32_t)nblocks;
-
     stamp(p, ST_PRE, st);
     const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
     {
@@ -902,15 +911,85 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
             default: launch_fixup<4>(p, src, nblocks, np, st); break;
         }
     }
-
     stamp(p, ST_HIST, st);
-    const uint32_t nhb = B * kMaxPlanes * g.nblk;
-    const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
     // (the list of k_hist's blocks sits in big_list until k_layout refills that array for k_encode; its count in work_ctr[2])
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
     hipLaunchKernelGGL(k_histlist, dim3((nhb + 255) / 256), dim3(256), 0, st, p->nzflag, p->nbuse, g, nhb, p->big_list, p->work_ctr + 2, p->psel);
-    hipLaunchKernelGGL(k_hist, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->hist, p->seghist, p->work_ctr, p->big_list,
-                       p->work_ctr + 2, p->lists, p->listinfo);
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+static uint32_t persistent_grid(const rspt_hip_packer* p, uint32_t nhb, uint32_t knob) {
+    const uint32_t persist = (uint32_t)(2 * p->num_cu) < nhb ? (uint32_t)(2 * p->num_cu) : nhb;  // 2 x 1024 threads fill a CU
+    return knob && knob < persist ? knob : persist;
+}
+
+static int phase_hist(rspt_hip_packer* p, uint32_t B, hipStream_t st) {
+    const Geom& g = p->g;
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
+    hipLaunchKernelGGL(k_hist, dim3(persistent_grid(p, nhb, p->hist_grid)), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->hist, p->seghist, p->work_ctr,
+                       p->big_list, p->work_ctr + 2, p->lists, p->listinfo);
     HIPCHK(p, hipGetLastError());  // (a failing launch is reported at its own stage)
+    return RSPT_HIP_OK;
+}
+
+static int phase_tree(rspt_hip_packer* p, uint32_t B, hipStream_t st) {
+    const Geom& g = p->g;
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
+    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase,
+                       p->zbuf[p->zset ^ 1], (uint32_t)p->zcap_words, p->psel);
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+static int phase_layout(rspt_hip_packer* p, uint32_t B, void* d_dst, size_t dst_stride, uint64_t* d_sizes, hipStream_t st) {
+    const Geom& g = p->g;
+    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
+    hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
+                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift, p->psel);
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+static int phase_small(rspt_hip_packer* p, uint32_t B, void* d_dst, size_t dst_stride, hipStream_t ss) {
+    const Geom& g = p->g;
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
+    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
+    const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
+    const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
+    hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, ss, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                       p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate, p->h_nsmall);
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+// `yield`: an eighth of the grid steps aside for k_encode_small running beside it on the side stream
+static int phase_encode(rspt_hip_packer* p, uint32_t B, void* d_dst, size_t dst_stride, hipStream_t st, uint32_t yield) {
+    const Geom& g = p->g;
+    const uint32_t nhb = B * kMaxPlanes * g.nblk;
+    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
+    hipLaunchKernelGGL(k_encode, dim3(persistent_grid(p, nhb, p->enc_grid)), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
+                       p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo, p->stamps, yield);
+    HIPCHK(p, hipGetLastError());
+    return RSPT_HIP_OK;
+}
+
+static int ensure_nsmall(rspt_hip_packer* p) {
+    if (!p->h_nsmall) {
+        if (hipHostMalloc((void**)&p->h_nsmall, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
+        *p->h_nsmall = 0xFFFFFFFFu;  // (unknown yet)
+    }
+    return RSPT_HIP_OK;
+}
+
+// one batch, start to end on one stream (the small-block encoder beside the big one on the handle's side stream)
+static int compress_batch_serial(rspt_hip_packer* p, const void* d_src, size_t nblocks, void* d_dst, size_t dst_stride, uint64_t* d_sizes, hipStream_t st) {
+    int rc = rspt_hip_reserve(p, nblocks);
+    if (rc) return rc;
+    HIPCHK(p, hipSetDevice(p->device));
+    const uint32_t B = (uint32_t)nblocks;
+    if ((rc = phase_front(p, (const uint8_t*)d_src, nblocks, st)) != 0) return rc;
+    if ((rc = phase_hist(p, B, st)) != 0) return rc;
 
     stamp(p, ST_TREE, st);
     if (p->psel & 256u) {  // (diagnostic builds only: time the front end and k_hist alone)
@@ -918,9 +997,7 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         if (p->profiling) p->ev_valid = true;
         return RSPT_HIP_OK;
     }
-    hipLaunchKernelGGL(k_tree, dim3((nhb + 3) / 4), dim3(256), 0, st, p->hist, p->planes, g, p->nbuse, p->nzflag, nhb, p->cw, p->tdesc, p->meta, p->seghist, p->segbase,
-                       p->zbuf[p->zset ^ 1], (uint32_t)p->zcap_words, p->psel);
-    HIPCHK(p, hipGetLastError());
+    if ((rc = phase_tree(p, B, st)) != 0) return rc;
     const int zset_next = p->zset ^ 1;
 
     stamp(p, ST_LAYOUT, st);
@@ -931,16 +1008,10 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         p->zset = zset_next;
         return RSPT_HIP_OK;
     }
-    WorkQueues* wq = reinterpret_cast<WorkQueues*>(p->work_ctr + 4);
-    hipLaunchKernelGGL(k_layout, dim3(B), dim3(256), 0, st, g, p->nbuse, p->meta, p->means, (uint8_t*)d_dst, (uint64_t)dst_stride, p->out_off,
-                       d_sizes, p->crc, p->nzflag, wq, p->big_list, p->small_list, p->plane_dirty, p->dirty_shift, p->psel);
-    HIPCHK(p, hipGetLastError());
+    if ((rc = phase_layout(p, B, d_dst, dst_stride, d_sizes, st)) != 0) return rc;
 
     stamp(p, ST_ENCODE, st);
-    if (!p->h_nsmall) {
-        if (hipHostMalloc((void**)&p->h_nsmall, sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return RSPT_HIP_ERR_ALLOC;
-        *p->h_nsmall = 0xFFFFFFFFu;  // (unknown yet)
-    }
+    if ((rc = ensure_nsmall(p)) != 0) return rc;
     // Both encoders depend on k_layout only.  The small-block one goes to the side stream (the big one yields it room) -- unless the
     // recent batches of this handle held no small blocks at all: the fork and join of a second stream cost ~10 us, an empty
     // kernel in line 2.  The guess only decides where the kernel runs.
@@ -950,15 +1021,9 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
         HIPCHK(p, hipEventRecord(p->ev_fork, st));
         HIPCHK(p, hipStreamWaitEvent(p->side, p->ev_fork, 0));
     }
-    {
-        const uint32_t want = (nhb + kSmallWaves - 1) / kSmallWaves;
-        const uint32_t sgrid = (uint32_t)(6 * p->num_cu) < want ? (uint32_t)(6 * p->num_cu) : want;  // ~22 KiB of LDS per workgroup
-        hipLaunchKernelGGL(k_encode_small, dim3(sgrid), dim3(kSmallWaves * 64), 0, ss, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off,
-                           p->crc, (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->small_list, p->ablate, p->h_nsmall);
-    }
+    if ((rc = phase_small(p, B, d_dst, dst_stride, ss)) != 0) return rc;
     if (side) HIPCHK(p, hipEventRecord(p->ev_join, p->side));
-    hipLaunchKernelGGL(k_encode, dim3(persist), dim3(kEncThreads), 0, st, p->planes, g, p->nzflag, p->meta, p->cw, p->tdesc, p->out_off, p->crc,
-                       (uint8_t*)d_dst, (uint64_t)dst_stride, wq, p->big_list, p->segbase, p->lists, p->listinfo, p->stamps);
+    if ((rc = phase_encode(p, B, d_dst, dst_stride, st, 1u)) != 0) return rc;
     stamp(p, ST_ENCODE_SMALL, st);
     if (side) HIPCHK(p, hipStreamWaitEvent(st, p->ev_join, 0));
     stamp(p, ST_COUNT, st);
@@ -967,6 +1032,14 @@ int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nb
     p->zero_ready[zset_next] = true;  // every launch went out: the other copy is zero when the next call starts
     p->zset = zset_next;
     return RSPT_HIP_OK;
+}
+
+int rspt_hip_compress_batch_dev(rspt_hip_packer* p, const void* d_src, size_t nblocks, void* d_dst, size_t dst_stride, uint64_t* d_sizes,
+                                void* stream) {
+    if (!p || !d_src || !d_dst || !d_sizes || nblocks == 0) return RSPT_HIP_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(d_src) & 15) return RSPT_HIP_ERR_ARG;  // tile loads are 16-byte aligned chunks
+    if (p->feed) return RSPT_HIP_ERR_ARG;  // (the feed owns the handle's workspace until rspt_hip_feed_end)
+    return compress_batch_serial(p, d_src, nblocks, d_dst, dst_stride, d_sizes, (hipStream_t)stream);
 }
 
 size_t rspt_hip_pack_bound(const rspt_hip_packer* p, size_t nblocks) {
@@ -1064,7 +1137,7 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
     int rc = ensure_host_staging(p);
     if (rc) return rc;
     HIPCHK(p, hipMemcpyAsync(p->h_src, src_host, p->g.block_bytes, hipMemcpyHostToDevice, p->stream));
-    rc = rspt_hip_compress_batch_dev(p, p->h_src, 1, p->h_dst, p->h_dst_cap, p->h_size, (void*)p->stream);
+    rc = compress_batch_serial(p, p->h_src, 1, p->h_dst, p->h_dst_cap, p->h_size, p->stream);
     if (rc) return rc;
     uint64_t sz = 0;
     uint32_t nb_now = 0;
@@ -1165,7 +1238,7 @@ static int compress_many_pipeline(rspt_hip_packer* p, const void* src_host, size
         HIPCHK(p, hipMemcpyAsync(p->m_src[slot], src + first * bb, cnt * bb, hipMemcpyHostToDevice, p->m_up));
         HIPCHK(p, hipEventRecord(p->m_ev_up[slot], p->m_up));
         HIPCHK(p, hipStreamWaitEvent(p->stream, p->m_ev_up[slot], 0));
-        rc = rspt_hip_compress_batch_dev(p, p->m_src[slot], cnt, p->m_dst[slot], p->m_stride, p->m_sizes[slot], (void*)p->stream);
+        rc = compress_batch_serial(p, p->m_src[slot], cnt, p->m_dst[slot], p->m_stride, p->m_sizes[slot], p->stream);
         if (rc) return rc;
         HIPCHK(p, hipMemcpyAsync(p->m_hsizes + (size_t)slot * C, p->m_sizes[slot], cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
         HIPCHK(p, hipEventRecord(p->m_ev_comp[slot], p->stream));
@@ -1255,7 +1328,7 @@ static int feed_launch(rspt_hip_packer* p, FeedSlot& s) {
     Feed* f = p->feed;
     HIPCHK(p, hipEventRecord(s.ev_up, p->m_up));
     HIPCHK(p, hipStreamWaitEvent(p->stream, s.ev_up, 0));
-    const int rc = rspt_hip_compress_batch_dev(p, s.d_src, s.count, s.d_dst, f->stride, s.d_sizes, (void*)p->stream);
+    const int rc = compress_batch_serial(p, s.d_src, s.count, s.d_dst, f->stride, s.d_sizes, p->stream);
     if (rc) return rc;
     HIPCHK(p, hipMemcpyAsync(s.h_sizes, s.d_sizes, s.count * sizeof(uint64_t), hipMemcpyDeviceToHost, p->stream));
     HIPCHK(p, hipMemcpyAsync(s.h_sizes + f->G, p->nb_state, sizeof(uint32_t), hipMemcpyDeviceToHost, p->stream));
@@ -1488,6 +1561,7 @@ int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t sr
 static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stride, const uint64_t* pidx, size_t packed_len, size_t nblocks,
                           void* d_dst, uint64_t* d_consumed, void* stream) {
     if (!p || !d_src || !d_dst || !d_consumed || nblocks == 0) return RSPT_HIP_ERR_ARG;
+    if (p->feed) return RSPT_HIP_ERR_ARG;  // (the feed owns the plane workspace until rspt_hip_feed_end)
     int rc = rspt_hip_reserve(p, nblocks);
     if (rc) return rc;
     HIPCHK(p, hipSetDevice(p->device));

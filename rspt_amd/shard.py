@@ -104,7 +104,9 @@ class LaggedGather:
     Here the sizes of step i travel by an all-gather on the device (ncclAllGather of the sizes) and a copy into
     page-locked host memory, both on a side stream; the host looks at them one step later -- when they have long arrived --
     and posts the payload of step i then, as one group of send / recv (ncclGroupStart ... ncclGroupEnd), again on the side
-    stream.  flush() posts the last step's payload.  The payload of a step therefore overlaps the kernels of the next one.
+    stream -- BEFORE that stream is made to wait for the kernels of step i+1, so the payload of a step overlaps the kernels of
+    the next one.  flush() posts the last step's payload.  `done_event` (cuda) is the event behind the payload group that
+    `step` / `flush` last returned: a consumer of the receive buffers waits on it (the next payload overwrites them).
 
         lag = LaggedGather(dst=0, recv_bufs=..., device=dev)        # recv_bufs[r]: bound-sized buffer per source rank (dst only)
         for i in steps:
@@ -116,7 +118,7 @@ class LaggedGather:
     Works over gloo with CPU tensors too (no streams: everything is immediate), which is how the CPU tests run it.
     """
 
-    def __init__(self, dst=0, group=None, recv_bufs=None, device=None):
+    def __init__(self, dst=0, group=None, recv_bufs=None, device=None, timing=False):
         import torch
         import torch.distributed as dist
 
@@ -134,7 +136,9 @@ class LaggedGather:
         self.slot_free = [None, None]
         self.pending = None  # (slot, packed tensor) whose payload has not been posted yet
         self.k = 0
-        self.payload_ms = []  # (start, end) event pairs of the payload groups (dst)
+        self.timing = timing  # keep (start, end) event pairs of the payload groups for mean_payload_ms() (benchmarking only)
+        self.payload_ms = []
+        self.done_event = None
         self.gathered_bytes = 0
 
     def _post_payload(self, slot, packed):
@@ -144,30 +148,41 @@ class LaggedGather:
             self.ev_sizes[slot].synchronize()  # (recorded a whole step ago: does not wait in the steady state)
         sizes = [int(x) for x in self.sizes_host[slot].tolist()]
         ops, out = [], None
-        if self.rank != self.dst:
-            ops.append(dist.P2POp(dist.isend, packed[: sizes[self.rank]], self.dst, self.group))
-        else:
+
+        def build():
+            nonlocal out
+            if self.rank != self.dst:
+                ops.append(dist.P2POp(dist.isend, packed[: sizes[self.rank]], self.dst, self.group))
+                return
             out = []
             for r in range(self.world):
                 if r == self.dst:
                     out.append((packed, sizes[r]))
                     continue
+                # (temporary receive buffers are allocated under the stream that uses them)
                 buf = self.recv_bufs[r] if self.recv_bufs is not None else torch.empty(sizes[r], dtype=torch.uint8, device=packed.device)
                 ops.append(dist.P2POp(dist.irecv, buf[: sizes[r]], r, self.group))
                 out.append((buf, sizes[r]))
             self.gathered_bytes = sum(n for _, n in out)
+
         if self.cuda:
             with torch.cuda.stream(self.side):
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(self.side)
+                build()
+                e0 = torch.cuda.Event(enable_timing=True) if self.timing else None
+                e1 = torch.cuda.Event(enable_timing=self.timing)
+                if e0 is not None:
+                    e0.record(self.side)
                 reqs = dist.batch_isend_irecv(ops) if ops else []
                 for q in reqs:
                     q.wait()  # (stream-ordered for nccl: no host wait)
                 e1.record(self.side)
-                self.payload_ms.append((e0, e1))
+                if self.timing:
+                    self.payload_ms.append((e0, e1))
+                    del self.payload_ms[:-256]
                 self.slot_free[slot] = e1
+                self.done_event = e1
         else:
+            build()
             for q in (dist.batch_isend_irecv(ops) if ops else []):
                 q.wait()
         return out
@@ -177,6 +192,8 @@ class LaggedGather:
         dist, torch = self.dist, self.torch
         slot = self.k & 1
         done = None
+        if self.pending is not None:  # the previous step's payload: posted before the side stream waits for this step's kernels
+            done = self._post_payload(*self.pending)
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))
@@ -190,8 +207,6 @@ class LaggedGather:
             parts = [torch.zeros(1, dtype=torch.int64) for _ in range(self.world)]
             dist.all_gather(parts, total.view(1), group=self.group)
             self.sizes_host[slot].copy_(torch.cat(parts))
-        if self.pending is not None:
-            done = self._post_payload(*self.pending)
         self.pending = (slot, packed)
         self.k += 1
         return done
