@@ -535,7 +535,7 @@ def main():
         achieved = own / (acc[dominant] * 1e-3) / 1e9
         pipeline_gbs = alg_bytes / (dt / args.steps) / 1e9  # the WHOLE path: algorithmic bytes over the timed step (launch gaps included)
         kernel_sum_ms = sum(acc.values())
-        traffic, traffic_note = None, None
+        traffic, traffic_note, traffic_pipeline = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         default_shape = (args.packer, args.workload, B, nch, ns, args.nb, args.bps) == ("xdelta_hzr", "c3", 64, 64, 65536, 3, 4)
         if os.path.exists(tpath):
@@ -547,6 +547,7 @@ def main():
                     traffic_note = "stale: counters collected on other kernel sources (%s)" % tj.get("_kernels_sha")
                 else:
                     traffic = tj.get(dominant)
+                    traffic_pipeline = sum(int(v) for k_, v in tj.items() if not k_.startswith("_"))  # every kernel of the launch sequence
                     traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at kernels_sha %s" % tj.get("_kernels_sha")
             except Exception:
                 traffic = None
@@ -587,7 +588,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
+                "traffic": traffic,  # HBM bytes of the DOMINANT kernel per launch (compare with kernel_algorithmic_bytes)
+                "traffic_pipeline": traffic_pipeline,  # ... of the whole launch sequence (compare with algorithmic_bytes_per_launch)
+                "traffic_over_algorithmic": round(traffic_pipeline / alg_bytes, 3) if traffic_pipeline else None,
                 "traffic_note": traffic_note,
                 "kernel_algorithmic_bytes": own,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -596,6 +599,12 @@ def main():
                 "pipeline_gbs": round(pipeline_gbs, 1),
                 "pipeline_frac": round(pipeline_gbs / HBM_PEAK_GBS, 4),
                 "device_copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                # which resource the STEP is bound by, from the counters rather than from the longest kernel: the share of the step
+                # that moving the pipeline's measured HBM bytes at this GPU's copy rate accounts for (well under 1: not HBM)
+                "hbm_time_share_of_step": round(traffic_pipeline / (copy_gbs * 1e9) / (dt / args.steps), 3) if (traffic_pipeline and copy_gbs) else None,
+                "step_bound": (("hbm" if traffic_pipeline / (copy_gbs * 1e9) / (dt / args.steps) >= 0.7 else
+                                "vector issue + barrier / LDS waits of the hzr stages (profiles/r03_notes.md 1b); HBM busy for the share above")
+                               if (traffic_pipeline and copy_gbs) else None),
                 "pipeline_frac_of_device_copy": round(pipeline_gbs / copy_gbs, 4) if copy_gbs else None,
             },
         }

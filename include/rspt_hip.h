@@ -150,10 +150,12 @@ int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t sr
  *                         full; rspt_hip_feed_submit launches a partly filled one (when no more blocks are expected soon).
  *   rspt_hip_feed_poll    report ONE finished block, in push order: returns 1 and sets *seq (0, 1, 2, ... in push order),
  *                         *dst_len and *status (RSPT_HIP_OK, or RSPT_HIP_ERR_DST_TOO_SMALL with *dst_len = the size needed
- *                         and nothing copied); returns 0 when none is ready yet; never waits.
+ *                         and nothing copied; or the status of a launch that failed -- rspt_hip_feed_push / _submit returned it
+ *                         when it happened -- for every block of that group, with *dst_len = 0); returns 0 when none is
+ *                         ready yet; never waits.
  *   rspt_hip_feed_flush   submit what is queued and wait until everything pushed so far can be polled
  *   rspt_hip_feed_end     flush, drop unpolled results, free the ring.
- * One feed per handle; the batch entry points must not be called on the handle while a feed is open. */
+ * One feed per handle; while a feed is open the batch and many-block entry points of the handle return RSPT_HIP_ERR_ARG. */
 int rspt_hip_feed_begin(rspt_hip_packer* p, size_t blocks_per_launch, size_t slots);
 int rspt_hip_feed_push(rspt_hip_packer* p, const void* src_host, void* dst_host, size_t dst_cap);
 int rspt_hip_feed_submit(rspt_hip_packer* p);
@@ -225,27 +227,47 @@ int rspt_hip_decompress_packed_dev(rspt_hip_packer* p, const void* d_packed, siz
  * contiguous shards of independent blocks (no data-path collective); what travels is the result: the sizes by
  * ncclAllGather, the payload as ONE group of ncclSend / ncclRecv straight from every peer to the root (a gatherv over the
  * direct xGMI links; no ring).  `comm` is the caller's ncclComm_t, passed as void* so that this header needs no RCCL
- * header; the library binds to the RCCL the process has loaded (librccl.so.1) at the first call and fails with
- * RSPT_HIP_ERR_UNSUPPORTED when there is none.
+ * header; the library binds to RCCL at the first call (see below which copy) and fails with RSPT_HIP_ERR_UNSUPPORTED when
+ * there is none.
  *
  *   rspt_hip_gather_sizes     d_total (device u64: this rank's container length, as rspt_hip_pack_batch_dev wrote it) ->
  *                             d_totals[world] on every rank, and -- if h_totals is not NULL -- a copy in the caller's
  *                             page-locked host array h_totals[world] (asynchronous: valid once `stream` has got there)
  *   rspt_hip_gather_payload   with the sizes known on the host: root receives rank r's container at
  *                             d_recv + r * recv_stride (its own is copied there too), the others send theirs.
- *                             recv_stride >= the largest container (rspt_hip_pack_bound() always suffices), the SAME value
- *                             on every rank: a container that does not fit makes every rank return
+ *                             recv_stride >= the largest container (rspt_hip_pack_bound() always suffices), a multiple of
+ *                             16 (rspt_hip_decompress_packed_dev wants 16-byte aligned containers; else RSPT_HIP_ERR_ARG),
+ *                             the SAME value on every rank: a container that does not fit makes every rank return
  *                             RSPT_HIP_ERR_DST_TOO_SMALL before anything is posted
  *   rspt_hip_gather_containers  both, with one stream synchronisation in between (the sizes must reach the host before
  *                             the transfers can be posted); h_totals[world] receives the sizes on every rank.
  *                             A caller that gathers every step posts the payload of step i after the sizes of step
  *                             i+1 instead (no synchronisation: see rspt_amd/shard.py LaggedGather for the pattern).
+ *   rspt_hip_gather_post_sizes / _post_payload / _wait   the same gather for a caller that gathers EVERY step, without a host
+ *                             synchronisation in the step (two slots, 0 and 1, alternate):
+ *                               step i:  ... compress + rspt_hip_pack_batch_dev on `stream` ...
+ *                                        rspt_hip_gather_post_payload(slot of step i-1)   -- its sizes arrived a step ago
+ *                                        rspt_hip_gather_post_sizes(slot of step i, stream)
+ *                               at the end: rspt_hip_gather_post_payload(last slot).
+ *                             Both run on a gather stream of the handle: post_sizes orders it behind `stream` (the pack),
+ *                             the payload of step i-1 is posted in front of that and overlaps the kernels of step i.
+ *                             post_payload reads the sizes on the host (waits for them only if they have not arrived),
+ *                             copies them to h_totals[world] if that is not NULL, and posts the transfers;
+ *                             rspt_hip_gather_wait(slot, stream) makes `stream` wait for the slot's payload (before the
+ *                             container buffer of that slot is written again, before d_recv is read).
+ * The library binds to the copy of RCCL the process has already mapped (where the caller's ncclComm_t came from); with none
+ * mapped it loads librccl.so.1; with two different copies mapped (e.g. a framework's bundled one next to /opt/rocm's) every
+ * gather call returns RSPT_HIP_ERR_UNSUPPORTED unless the environment variable RSPT_RCCL_LIB names the one to use.
  * All ranks must make the same calls in the same order.  Asynchronous on `stream` except where said. */
 int rspt_hip_gather_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, uint64_t* d_totals, uint64_t* h_totals, void* stream);
 int rspt_hip_gather_payload(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* h_totals,
                             void* d_recv, size_t recv_stride, void* stream);
 int rspt_hip_gather_containers(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, const uint64_t* d_total,
                                void* d_recv, size_t recv_stride, uint64_t* h_totals, void* stream);
+int rspt_hip_gather_post_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, int slot, void* stream);
+int rspt_hip_gather_post_payload(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, int slot, void* d_recv,
+                                 size_t recv_stride, uint64_t* h_totals);
+int rspt_hip_gather_wait(rspt_hip_packer* p, int slot, void* stream);
 
 /* ---- optional stage in front of compress: the reference's IIR pre-filter ---------------------------------------
  * Replaces the filter step of the reference's own pipeline (lib_rspt_test/rspt_test.cpp:116-136): i_filter::new_iir

@@ -26,6 +26,7 @@ C_ABI_SYMBOLS = [
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
     "rspt_hip_compress_many", "rspt_hip_decompress_many", "rspt_hip_gather_sizes", "rspt_hip_gather_payload", "rspt_hip_gather_containers",
+    "rspt_hip_gather_post_sizes", "rspt_hip_gather_post_payload", "rspt_hip_gather_wait",
     "rspt_hip_feed_begin", "rspt_hip_feed_push", "rspt_hip_feed_submit", "rspt_hip_feed_poll", "rspt_hip_feed_flush", "rspt_hip_feed_end",
 ]
 

@@ -40,7 +40,9 @@ def stale():
 
 def build(force=False, verbose=False):
     if "-DRSPT_DIAG" in os.environ.get("RSPT_EXTRA_FLAGS", "").split():
-        return build_diag(verbose)
+        # the diagnostic library (timing probes that skip work) must never become what api.lib() loads
+        raise RuntimeError("rspt_amd.build: -DRSPT_DIAG does not belong in RSPT_EXTRA_FLAGS; build the diagnostic library with "
+                           "`python -m rspt_amd.build --diag` and load it through RSPT_HIP_LIB")
     if not force and not stale():
         return LIB
     with open(LIB + ".lock", "w") as lk:
@@ -70,13 +72,39 @@ DIAG_LIB = os.path.join(HERE, "librspt_hip_diag.so")
 
 def build_diag(verbose=False):
     """The diagnostic build (-DRSPT_DIAG: timing probes that skip work, tuning knobs from the environment) never replaces the
-    product library: it goes to librspt_hip_diag.so, which is only ever loaded through RSPT_HIP_LIB."""
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    product library: it goes to librspt_hip_diag.so, which is only ever loaded through RSPT_HIP_LIB.  Same care as build():
+    a content stamp, a file lock, publication by atomic rename."""
     flags = [f for f in os.environ.get("RSPT_EXTRA_FLAGS", "").split() if f != "-DRSPT_DIAG"]
-    cmd = [hipcc] + FLAGS + ["-DRSPT_DIAG"] + flags + ["-o", DIAG_LIB] + [os.path.join(CSRC, f) for f in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    stamp = DIAG_LIB + ".src-sha"
+    h = hashlib.sha256(("diag " + " ".join(FLAGS + sorted(flags))).encode())
+    for p in [os.path.join(CSRC, f) for f in DEPS] + INCLUDES:
+        if os.path.exists(p):
+            h.update(os.path.basename(p).encode())
+            h.update(open(p, "rb").read())
+    fp = h.hexdigest()
+
+    def fresh():
+        return os.path.exists(DIAG_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == fp
+
+    if fresh():
+        return DIAG_LIB
+    with open(DIAG_LIB + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if fresh():
+                return DIAG_LIB
+            hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+            tmp = "%s.tmp.%d" % (DIAG_LIB, os.getpid())
+            cmd = [hipcc] + FLAGS + ["-DRSPT_DIAG"] + flags + ["-o", tmp] + [os.path.join(CSRC, f) for f in SOURCES]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(tmp, DIAG_LIB)
+            with open(stamp + ".tmp", "w") as f:
+                f.write(fp + "\n")
+            os.replace(stamp + ".tmp", stamp)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
     return DIAG_LIB
 
 

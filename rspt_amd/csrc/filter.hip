@@ -217,10 +217,13 @@ struct IirPipeLds {
     int32_t out[2][kIirChunk][64];
     double xlast[5][64];  // the channel's last inputs, newest first (shared mode: the x ring the next channel's initialisation starts from)
 };
+// ~98.5 KiB of static LDS: one workgroup per CU, and only on a part with more than 64 KiB per workgroup (gfx950: 160 KiB)
+static_assert(sizeof(IirPipeLds) <= 160 * 1024, "k_iir_pipe: the tiles must fit one CU's LDS");
 
 template <int BPS, int NC, bool SHARED, bool ALIGNED>
 __global__ __launch_bounds__(kIirThreads) void k_iir_pipe(uint8_t* __restrict__ buf, uint32_t nch, uint32_t ns, uint64_t block_bytes, IirCoef c, uint32_t nblocks,
                                                  uint32_t lanes_per_wg) {
+    static_assert(NC >= 2 && NC <= 5, "IirPipeLds::xlast holds five inputs per channel");
     __shared__ IirPipeLds L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

@@ -9,6 +9,9 @@
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <link.h>
+#include <climits>
+#include <string>
 
 #include <cmath>
 #include <cstdio>
@@ -190,6 +193,13 @@ struct rspt_hip_packer {
     struct Feed* feed = nullptr;              // rspt_hip_feed_*: a ring of block groups in flight
     uint64_t* gat_totals = nullptr;           // device [gat_world]: container lengths of all ranks (rspt_hip_gather_containers)
     int gat_world = 0;
+    // rspt_hip_gather_post_*: two slots of sizes (device + page-locked host), events, the gather stream
+    uint64_t* lag_dtotals[2] = {nullptr, nullptr};
+    uint64_t* lag_htotals[2] = {nullptr, nullptr};
+    hipEvent_t lag_ev_in[2] = {}, lag_ev_sizes[2] = {}, lag_ev_payload[2] = {};
+    bool lag_posted[2] = {false, false};
+    hipStream_t lag_stream = nullptr;
+    int lag_world = 0;
     size_t m_chunk = 0, m_stride = 0;
     hipStream_t m_up = nullptr, m_down = nullptr;
     hipEvent_t m_ev_up[2] = {}, m_ev_comp[2] = {}, m_ev_down[2] = {};
@@ -747,6 +757,15 @@ void rspt_hip_packer_destroy(rspt_hip_packer* p) {
     if (p->feed) rspt_hip_feed_end(p);
     free_many(p);
     hipFree(p->gat_totals);
+    if (p->lag_stream) hipStreamSynchronize(p->lag_stream);
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->lag_dtotals[i]);
+        if (p->lag_htotals[i]) hipHostFree(p->lag_htotals[i]);
+        if (p->lag_ev_in[i]) hipEventDestroy(p->lag_ev_in[i]);
+        if (p->lag_ev_sizes[i]) hipEventDestroy(p->lag_ev_sizes[i]);
+        if (p->lag_ev_payload[i]) hipEventDestroy(p->lag_ev_payload[i]);
+    }
+    if (p->lag_stream) hipStreamDestroy(p->lag_stream);
     for (int i = 0; i <= ST_COUNT; ++i)
         if (p->ev[i]) hipEventDestroy(p->ev[i]);
     if (p->side) {
@@ -1174,8 +1193,8 @@ static int ensure_many(rspt_hip_packer* p) {
     for (int i = 0; i < 2; ++i) ok &= hipMalloc(&p->m_idx[i], (4 + 2 * chunk) * sizeof(uint64_t)) == hipSuccess;
     ok &= hipHostMalloc((void**)&p->m_hsizes, 2 * chunk * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
     ok &= hipHostMalloc((void**)&p->m_hidx, 2 * (4 + 2 * chunk) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
-    ok &= hipStreamCreateWithFlags(&p->m_up, hipStreamNonBlocking) == hipSuccess;
-    ok &= hipStreamCreateWithFlags(&p->m_down, hipStreamNonBlocking) == hipSuccess;
+    if (!p->m_up) ok &= hipStreamCreateWithFlags(&p->m_up, hipStreamNonBlocking) == hipSuccess;  // (rspt_hip_feed_begin may have made them)
+    if (!p->m_down) ok &= hipStreamCreateWithFlags(&p->m_down, hipStreamNonBlocking) == hipSuccess;
     if (!ok) {  // nothing half-made stays behind: a retry starts from null fields instead of allocating over live pointers
         free_many(p);
         return RSPT_HIP_ERR_ALLOC;
@@ -1189,6 +1208,7 @@ static int compress_many_pipeline(rspt_hip_packer* p, const void* src_host, size
 
 int rspt_hip_compress_many(rspt_hip_packer* p, const void* src_host, size_t nblocks, void* dst_host, size_t dst_stride, size_t* dst_len) {
     if (!p || !src_host || !dst_host || !dst_len || nblocks == 0) return RSPT_HIP_ERR_ARG;
+    if (p->feed) return RSPT_HIP_ERR_ARG;  // (the feed owns the workspace and the copy streams until rspt_hip_feed_end)
     HIPCHK(p, hipSetDevice(p->device));
     int rc = ensure_many(p);
     if (rc) return rc;
@@ -1267,6 +1287,7 @@ struct FeedSlot {
     std::vector<void*> dst_host;
     std::vector<size_t> dst_cap;
     size_t count = 0, delivered = 0, first_seq = 0;
+    int error = 0;  // the group's launch failed: every block of it is reported with this status
     hipEvent_t ev_up = nullptr, ev_comp = nullptr, ev_down = nullptr;
 };
 struct Feed {
@@ -1344,6 +1365,10 @@ int rspt_hip_feed_submit(rspt_hip_packer* p) {
     FeedSlot& s = f->slots[f->tail];
     if (s.state != FeedSlot::FILLING || s.count == 0) return RSPT_HIP_OK;
     const int rc = feed_launch(p, s);
+    if (rc) {  // nothing of this group will arrive: its blocks are reported by rspt_hip_feed_poll with the failure as their status
+        s.error = rc;
+        s.state = FeedSlot::DONE;
+    }
     f->tail = (f->tail + 1) % f->slots.size();
     return rc;
 }
@@ -1357,6 +1382,7 @@ int rspt_hip_feed_push(rspt_hip_packer* p, const void* src_host, void* dst_host,
     if (s.state == FeedSlot::FREE) {
         s.state = FeedSlot::FILLING;
         s.count = s.delivered = 0;
+        s.error = 0;
         s.first_seq = f->next_seq;
     }
     const size_t i = s.count;
@@ -1417,9 +1443,12 @@ int rspt_hip_feed_poll(rspt_hip_packer* p, size_t* seq, size_t* dst_len, int* st
     FeedSlot& s = f->slots[f->head];
     if (s.state != FeedSlot::DONE) return 0;
     const size_t i = s.delivered;
-    const uint64_t sz = s.h_sizes[i];
+    const uint64_t sz = s.error ? 0 : s.h_sizes[i];
     *seq = s.first_seq + i;
-    if ((sz >> 63) || sz > s.dst_cap[i]) {
+    if (s.error) {
+        *dst_len = 0;
+        *status = s.error;
+    } else if ((sz >> 63) || sz > s.dst_cap[i]) {
         *dst_len = (sz >> 63) ? 0 : (size_t)sz;
         *status = RSPT_HIP_ERR_DST_TOO_SMALL;
     } else {
@@ -1545,6 +1574,7 @@ static int decompress_many_pipeline(rspt_hip_packer* p, const void* src_host, si
 int rspt_hip_decompress_many(rspt_hip_packer* p, const void* src_host, size_t src_stride, const size_t* src_len, size_t nblocks, void* dst_host,
                              size_t* consumed) {
     if (!p || !src_host || !dst_host || !consumed || nblocks == 0 || src_stride == 0) return RSPT_HIP_ERR_ARG;
+    if (p->feed) return RSPT_HIP_ERR_ARG;  // (the feed owns the workspace and the copy streams until rspt_hip_feed_end)
     HIPCHK(p, hipSetDevice(p->device));
     int rc = ensure_many(p);
     if (rc) return rc;
@@ -1714,7 +1744,10 @@ int rspt_hip_iir_prefilter_batch_dev(rspt_hip_packer* p, void* d_buf, size_t nbl
 }
 
 // ---- multi-GPU gather over RCCL.  RCCL is bound at run time: a process that never gathers (the C++ drop-in on one
-// GPU, the tests on the CPU box) does not load it, and a process that does gather uses the very library its ncclComm_t came from.
+// GPU, the tests on the CPU box) does not load it.  A communicator must never cross library instances -- an ncclComm_t made by one
+// copy of RCCL is garbage to another (PyTorch wheels bundle their own librccl.so next to /opt/rocm's) -- so the binding goes to the
+// copy the process has ALREADY mapped (that is where the caller's ncclComm_t came from); only a process without any gets
+// librccl.so.1 from the loader's path; a process with two different copies mapped is refused unless RSPT_RCCL_LIB names the one.
 namespace {
 struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
@@ -1725,11 +1758,35 @@ struct Rccl {
     bool ok = false;
 };
 constexpr int kNcclUint8 = 1, kNcclUint64 = 5;  // ncclDataType_t (rccl.h)
-const Rccl& rccl() {
+int collect_rccl(struct dl_phdr_info* info, size_t, void* data) {
+    auto* v = static_cast<std::vector<std::string>*>(data);
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl.so")) {
+        char real[PATH_MAX];
+        const std::string path = realpath(info->dlpi_name, real) ? real : info->dlpi_name;
+        bool seen = false;
+        for (const auto& q : *v) seen = seen || q == path;
+        if (!seen) v->push_back(path);
+    }
+    return 0;
+}
+}  // namespace
+static const Rccl& rccl() {
     static Rccl r = [] {
         Rccl q;
-        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        void* h = nullptr;
+        if (const char* want = getenv("RSPT_RCCL_LIB")) {
+            h = dlopen(want, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            std::vector<std::string> mapped;
+            dl_iterate_phdr(collect_rccl, &mapped);
+            if (mapped.size() > 1) return q;  // two copies in one process: which one made the caller's communicator is not ours to guess
+            if (mapped.size() == 1) {
+                h = dlopen(mapped[0].c_str(), RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);  // the instance already in the process
+            } else {
+                h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            }
+        }
         if (!h) return q;
         q.AllGather = reinterpret_cast<decltype(q.AllGather)>(dlsym(h, "ncclAllGather"));
         q.Send = reinterpret_cast<decltype(q.Send)>(dlsym(h, "ncclSend"));
@@ -1741,7 +1798,6 @@ const Rccl& rccl() {
     }();
     return r;
 }
-}  // namespace
 
 int rspt_hip_gather_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, uint64_t* d_totals, uint64_t* h_totals, void* stream) {
     if (!p || !comm || world < 1 || !d_total || !d_totals) return RSPT_HIP_ERR_ARG;
@@ -1758,6 +1814,7 @@ int rspt_hip_gather_payload(rspt_hip_packer* p, void* comm, int rank, int world,
                             void* d_recv, size_t recv_stride, void* stream) {
     if (!p || !comm || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world || !d_packed || !h_totals) return RSPT_HIP_ERR_ARG;
     if (rank == root && !d_recv) return RSPT_HIP_ERR_ARG;
+    if (recv_stride & 15) return RSPT_HIP_ERR_ARG;  // (every rank's container must land 16-byte aligned: rspt_hip_decompress_packed_dev)
     const Rccl& R = rccl();
     if (!R.ok) return RSPT_HIP_ERR_UNSUPPORTED;
     HIPCHK(p, hipSetDevice(p->device));
@@ -1795,6 +1852,67 @@ int rspt_hip_gather_containers(rspt_hip_packer* p, void* comm, int rank, int wor
     if (rc == RSPT_HIP_OK && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = RSPT_HIP_ERR_LAUNCH;  // the sizes are on the host now
     if (rc == RSPT_HIP_OK) rc = rspt_hip_gather_payload(p, comm, rank, world, root, d_packed, h_totals, d_recv, recv_stride, stream);
     return rc;
+}
+
+// The same gather without a host synchronisation in the step (what rspt_amd/shard.py LaggedGather does over torch.distributed):
+// the sizes of step i travel by a device all-gather and a copy into page-locked memory of the handle, on the handle's own gather
+// stream behind an event on `stream`; the host reads them when it posts the payload -- one step later, when they have long
+// arrived -- again on the gather stream, so that the payload of step i overlaps the kernels of step i + 1.
+static int gather_lag_ensure(rspt_hip_packer* p, int world) {
+    if (p->lag_world >= world && p->lag_stream) return RSPT_HIP_OK;
+    for (int i = 0; i < 2; ++i) {
+        hipFree(p->lag_dtotals[i]);
+        if (p->lag_htotals[i]) hipHostFree(p->lag_htotals[i]);
+        p->lag_dtotals[i] = p->lag_htotals[i] = nullptr;
+    }
+    p->lag_world = 0;
+    bool ok = true;
+    for (int i = 0; i < 2; ++i) {
+        ok &= hipMalloc(&p->lag_dtotals[i], (size_t)world * sizeof(uint64_t)) == hipSuccess;
+        ok &= hipHostMalloc((void**)&p->lag_htotals[i], (size_t)world * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
+        if (!p->lag_ev_in[i]) ok &= hipEventCreateWithFlags(&p->lag_ev_in[i], hipEventDisableTiming) == hipSuccess;
+        if (!p->lag_ev_sizes[i]) ok &= hipEventCreateWithFlags(&p->lag_ev_sizes[i], hipEventDisableTiming) == hipSuccess;
+        if (!p->lag_ev_payload[i]) ok &= hipEventCreateWithFlags(&p->lag_ev_payload[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!p->lag_stream) ok &= hipStreamCreateWithFlags(&p->lag_stream, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) return RSPT_HIP_ERR_ALLOC;
+    p->lag_world = world;
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_gather_post_sizes(rspt_hip_packer* p, void* comm, int world, const uint64_t* d_total, int slot, void* stream) {
+    if (!p || !comm || world < 1 || !d_total || slot < 0 || slot > 1) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    int rc = gather_lag_ensure(p, world);
+    if (rc) return rc;
+    HIPCHK(p, hipEventRecord(p->lag_ev_in[slot], (hipStream_t)stream));  // d_total (and the container) are written on `stream`
+    HIPCHK(p, hipStreamWaitEvent(p->lag_stream, p->lag_ev_in[slot], 0));
+    rc = rspt_hip_gather_sizes(p, comm, world, d_total, p->lag_dtotals[slot], p->lag_htotals[slot], (void*)p->lag_stream);
+    if (rc) return rc;
+    HIPCHK(p, hipEventRecord(p->lag_ev_sizes[slot], p->lag_stream));
+    p->lag_posted[slot] = true;
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_gather_post_payload(rspt_hip_packer* p, void* comm, int rank, int world, int root, const void* d_packed, int slot, void* d_recv,
+                                 size_t recv_stride, uint64_t* h_totals) {
+    if (!p || slot < 0 || slot > 1 || !p->lag_posted[slot] || world > p->lag_world) return RSPT_HIP_ERR_ARG;
+    HIPCHK(p, hipSetDevice(p->device));
+    HIPCHK(p, hipEventSynchronize(p->lag_ev_sizes[slot]));  // (a step old in the steady state: does not wait)
+    p->lag_posted[slot] = false;
+    if (h_totals) memcpy(h_totals, p->lag_htotals[slot], (size_t)world * sizeof(uint64_t));
+    const int rc = rspt_hip_gather_payload(p, comm, rank, world, root, d_packed, p->lag_htotals[slot], d_recv, recv_stride, (void*)p->lag_stream);
+    if (rc) return rc;
+    HIPCHK(p, hipEventRecord(p->lag_ev_payload[slot], p->lag_stream));
+    return RSPT_HIP_OK;
+}
+
+int rspt_hip_gather_wait(rspt_hip_packer* p, int slot, void* stream) {
+    if (!p || slot < 0 || slot > 1) return RSPT_HIP_ERR_ARG;
+    if (!p->lag_ev_payload[slot]) return RSPT_HIP_OK;  // (nothing was ever posted)
+    HIPCHK(p, hipSetDevice(p->device));
+    HIPCHK(p, hipStreamWaitEvent((hipStream_t)stream, p->lag_ev_payload[slot], 0));
+    return RSPT_HIP_OK;
 }
 
 long long rspt_hip_debug_read(rspt_hip_packer* p, int which, void* host_buf, size_t cap) {

@@ -240,3 +240,14 @@ def iir_cases():
     add("rand7x1001_i8_order1", 1, 7, 1001, ([1.0, -0.9], [0.05, 0.05]), 50, _rand_native(7, 1001, 1, 51, 100))
     add("rand3x777_i24_order3", 3, 3, 777, ([1.0, -1.2, 0.5, -0.05], [0.1, 0.2, 0.2, 0.1]), 0, _rand_native(3, 777, 3, 52, 1 << 20))
     return C
+
+
+def iir_big_case():
+    """The pre-filter at the size at which round 2's kernel was wrong: one full 64 ch x 65536 int32 block (ECG-like synthetic,
+    SURVEY 8d), the harness's band-pass and history length (rspt_test.cpp:123-129).  Fused multiply-adds moved an output by one
+    count about once in two million samples -- none of the small fixtures above ever showed it."""
+    return dict(name="synth64x65536_i32_bandpass", bps=4, nch=64, ns=65536, n=IIR_BANDPASS[0], d=IIR_BANDPASS[1], init=2000, block=5)
+
+
+def iir_big_data(c):
+    return synth.synth_native(c["nch"], c["ns"], c["block"], bps=c["bps"], ecg=True).numpy()

@@ -3,12 +3,16 @@
 // (rspt_hip_compress_batch_dev), packs the streams into a container (rspt_hip_pack_batch_dev) and the containers travel to
 // rank 0 over RCCL (rspt_hip_gather_containers: ncclAllGather of the sizes, one group of ncclSend / ncclRecv for the payload).
 // Rank 0 decodes every gathered container on its own device (rspt_hip_decompress_packed_dev) and compares with the input.
-// Runs with however many devices are visible (a world of one included).  Exit code 0 = all good.
+// Then three steps of the lagged form (rspt_hip_gather_post_sizes / _post_payload / _wait: no host synchronisation in a step,
+// the payload of step i posted during step i + 1), the containers of the last two steps decoded on rank 0.
+// Runs with however many devices are visible (a world of one included).  Exit code 0 = all good.  A rank that fails ends the
+// whole process at once: its peers would otherwise wait in a collective it never enters.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -39,9 +43,11 @@ int main() {
     for (int r = 0; r < world; ++r)
         th.emplace_back([&, r]() {
             auto check = [&](bool ok, const char* what) {
-                if (!ok && !fail[r]) {
+                if (!ok) {
                     fail[r] = 1;
                     std::fprintf(stderr, "rank %d: %s failed\n", r, what);
+                    std::fflush(stderr);
+                    std::_Exit(1);  // (never leave the other ranks waiting in a collective)
                 }
                 return ok;
             };
@@ -82,6 +88,47 @@ int main() {
                 }
                 hipFree(d_back);
                 hipFree(d_used);
+            }
+            // ---- the lagged form, three steps: two container buffers and (on rank 0) two receive areas alternate ----
+            {
+                uint8_t *packed2[2] = {d_packed, nullptr}, *recv2[2] = {d_recv, nullptr};
+                uint64_t* total2[2] = {d_total, nullptr};
+                hipMalloc(&packed2[1], bound);
+                hipMalloc(&total2[1], 8);
+                if (r == 0) hipMalloc(&recv2[1], (size_t)world * bound);
+                std::vector<uint64_t> ht(2 * world);
+                const int steps = 3;
+                for (int i = 0; i < steps; ++i) {
+                    const int slot = i & 1;
+                    check(rspt_hip_gather_wait(pk, slot, st) == RSPT_HIP_OK, "gather_wait");  // the payload of step i - 2 has left packed2[slot]
+                    check(rspt_hip_compress_batch_dev(pk, d_src, count, d_dst, stride, d_sizes, st) == RSPT_HIP_OK, "compress_batch (lagged)");
+                    check(rspt_hip_pack_batch_dev(pk, d_dst, stride, d_sizes, count, packed2[slot], total2[slot], st) == RSPT_HIP_OK, "pack_batch (lagged)");
+                    if (i) check(rspt_hip_gather_post_payload(pk, comms[r], r, world, 0, packed2[slot ^ 1], slot ^ 1, recv2[slot ^ 1], bound, &ht[(slot ^ 1) * world]) == RSPT_HIP_OK, "post_payload");
+                    check(rspt_hip_gather_post_sizes(pk, comms[r], world, total2[slot], slot, st) == RSPT_HIP_OK, "post_sizes");
+                }
+                const int last = (steps - 1) & 1;
+                check(rspt_hip_gather_post_payload(pk, comms[r], r, world, 0, packed2[last], last, recv2[last], bound, &ht[last * world]) == RSPT_HIP_OK, "post_payload (flush)");
+                for (int slot = 0; slot < 2; ++slot) check(rspt_hip_gather_wait(pk, slot, st) == RSPT_HIP_OK, "gather_wait (end)");
+                check(hipStreamSynchronize(st) == hipSuccess, "sync (lagged)");
+                if (r == 0) {
+                    uint8_t* d_back;
+                    uint64_t* d_used;
+                    hipMalloc(&d_back, nblocks * block_bytes);
+                    hipMalloc(&d_used, nblocks * 8);
+                    std::vector<uint8_t> back(block_bytes * nblocks);
+                    for (int slot = 0; slot < 2; ++slot)
+                        for (int q = 0; q < world; ++q) {
+                            const size_t qf = (size_t)q * nblocks / world, qc = (size_t)(q + 1) * nblocks / world - qf;
+                            check(ht[slot * world + q] == ht[q] && ht[q] >= 32 + 16 * qc && ht[q] <= bound, "sizes of the lagged steps");  // (same input, same carried nb)
+                            check(rspt_hip_decompress_packed_dev(pk, recv2[slot] + (size_t)q * bound, ht[slot * world + q], qc, d_back, d_used, st) == RSPT_HIP_OK, "decompress_packed (lagged)");
+                            hipMemcpyAsync(back.data(), d_back, qc * block_bytes, hipMemcpyDeviceToHost, st);
+                            hipStreamSynchronize(st);
+                            check(std::memcmp(back.data(), input.data() + qf * nch * ns, qc * block_bytes) == 0, "round trip of a shard gathered by the lagged form");
+                        }
+                    hipFree(d_back);
+                    hipFree(d_used);
+                }
+                hipFree(packed2[1]); hipFree(total2[1]); hipFree(recv2[1]);
             }
             hipFree(d_src); hipFree(d_dst); hipFree(d_packed); hipFree(d_sizes); hipFree(d_total); hipFree(d_recv);
             hipHostFree(h_totals);

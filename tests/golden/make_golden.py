@@ -115,6 +115,24 @@ def main():
             "xdelta_size": len(s), "xdelta_fnv1a": orc.fnv1a(s),
         }
         print("%-28s filtered crc %08x xdelta %d" % (c["name"], zlib.crc32(filt), len(s)))
+    # the pre-filter at full size (CRCs only): the harness's shared filter object (what the reference runs), a fresh filter per
+    # channel (the reference run channel by channel on one-channel blocks), each with and without the history initialisation
+    # (without it the GPU takes the one-thread-per-channel kernel)
+    c = cases.iir_big_case()
+    data = cases.iir_big_data(c)
+    x = data.view(np.int32).reshape(c["ns"], c["nch"])
+    out["iir_big"] = {c["name"]: {"bps": c["bps"], "nch": c["nch"], "ns": c["ns"], "n": c["n"], "d": c["d"], "block": c["block"],
+                                  "in_crc32": zlib.crc32(data.tobytes()), "modes": {}}}
+    for init in (c["init"], 0):
+        shared = ref.iir_prefilter(data, c["bps"], c["nch"], c["ns"], c["n"], c["d"], init)
+        per = np.empty_like(x)
+        for ch in range(c["nch"]):
+            one = np.ascontiguousarray(x[:, ch]).view(np.uint8)
+            per[:, ch] = np.frombuffer(ref.iir_prefilter(one, c["bps"], 1, c["ns"], c["n"], c["d"], init), dtype=np.int32)
+        per = per.tobytes()
+        for mode, buf in (("shared", shared), ("per_channel", per)):
+            out["iir_big"][c["name"]]["modes"]["%s_init%d" % (mode, init)] = {"crc32": zlib.crc32(buf), "fnv1a": orc.fnv1a(buf)}
+            print("%-28s %-18s crc %08x" % (c["name"], "%s init %d" % (mode, init), zlib.crc32(buf)))
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "golden.json"))

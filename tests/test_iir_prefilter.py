@@ -108,3 +108,37 @@ def test_gpu_prefilter_rejects_bad_orders(api):
         with pytest.raises(api.RsptHipError):
             pk.iir_prefilter_batch(d_buf, [1.0] * k, [1.0] * k)
     pk.close()
+
+
+# ---- the full-size block: the size at which fused multiply-adds once flipped output counts (no small fixture ever did) ----
+BIG_MODES = [("shared", 2000), ("per_channel", 2000), ("shared", 0), ("per_channel", 0)]
+
+
+@pytest.mark.parametrize("mode,init", BIG_MODES)
+def test_restatement_matches_reference_at_full_size(orc, golden, mode, init):
+    c = cases.iir_big_case()
+    g = golden["iir_big"][c["name"]]
+    data = cases.iir_big_data(c)
+    assert zlib.crc32(data.tobytes()) == g["in_crc32"]
+    filt = orc.iir_prefilter(data, c["bps"], c["nch"], c["ns"], c["n"], c["d"], init, shared_state=mode == "shared")
+    want = g["modes"]["%s_init%d" % (mode, init)]
+    assert zlib.crc32(filt) == want["crc32"] and orc.fnv1a(filt) == want["fnv1a"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,init", BIG_MODES)
+def test_gpu_prefilter_full_size_block(api, golden, mode, init):
+    """64 ch x 65536 int32 through rspt_hip_iir_prefilter_batch_dev, both modes, the six-wave kernel (history
+    initialisation) and the one-thread-per-channel kernel (none): CRCs of the real reference's filtered block"""
+    import torch
+
+    c = cases.iir_big_case()
+    want = golden["iir_big"][c["name"]]["modes"]["%s_init%d" % (mode, init)]
+    data = cases.iir_big_data(c)
+    pk = api.new_xdelta_hzr(c["bps"], c["nch"], c["ns"], 3)
+    d_buf = torch.from_numpy(np.stack([data, data])).cuda()
+    pk.iir_prefilter_batch(d_buf, c["n"], c["d"], init, per_channel=mode == "per_channel")
+    torch.cuda.synchronize()
+    for b in range(2):
+        assert zlib.crc32(d_buf[b].cpu().numpy().tobytes()) == want["crc32"], "block %d" % b
+    pk.close()

@@ -82,3 +82,42 @@ def test_the_barrier_check_sees_the_hazard(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_barrier_waits.py"), str(f)], capture_output=True, text=True)
         assert r.returncode == want, (want, r.stdout)
         assert ("1 barriers, %d unpublished" % want) in r.stdout, r.stdout
+
+
+def _kernel_bodies(asm_path):
+    """mangled kernel name -> its instruction lines (from the symbol's label to its .Lfunc_end)"""
+    import re
+
+    bodies, name, cur = {}, None, []
+    for ln in open(asm_path):
+        m = re.match(r"^(_Z\w+):\s", ln)
+        if m and name is None:
+            name, cur = m.group(1), []
+            continue
+        if name is not None:
+            if ln.startswith(".Lfunc_end"):
+                bodies[name] = cur
+                name = None
+            else:
+                cur.append(ln.strip())
+    return bodies
+
+
+def test_no_fused_multiply_add_where_the_reference_rounds_twice(device_asm):
+    """The IIR pre-filter and the dct's table path restate the reference's arithmetic operation for operation: every product
+    and every sum is rounded on its own (iir_filter.cpp:46-116, signal_packer_dct.cpp:76-87).  hipcc contracts a * b + c into
+    one FMA by default and HIP's __dmul_rn / __dadd_rn do not stop it: round 2's k_iir held 83 v_fma_f64 and moved one output
+    count per ~2 M samples -- on no fixture, only on the full-size batch.  The ISA of these kernels must hold no fp FMA."""
+    import re
+
+    bodies = _kernel_bodies(device_asm)
+    fma = re.compile(r"^v_(fma|fmac|mad|mac|pk_fma)_(f64|f32|legacy_f32)\b")
+    iir = [k for k in bodies if "k_iir" in k]
+    dct = [k for k in bodies if re.search(r"5k_dctILb[01]E", k)]  # rspt::k_dct<true|false>: the dense-table transform
+    assert len(iir) >= 64 and len(dct) == 2, (len(iir), dct)  # (k_iir / k_iir_pipe x sample width x order x mode)
+    for k in iir + dct:
+        hits = [ln for ln in bodies[k] if fma.match(ln)]
+        assert not hits, (k, hits[:4])
+        # and the arithmetic is there at all: separate fp64 multiplies and adds
+        assert any(ln.startswith("v_mul_f64") for ln in bodies[k]) or "k_dct" in k, k
+        assert any(ln.startswith("v_add_f64") for ln in bodies[k]), k
