@@ -357,6 +357,21 @@ static void launch_dct_fft(rspt_hip_packer* p, uint32_t B, const int32_t* in, in
     }
 }
 
+// WHT of rows longer than 65536 points, in place in `planar` (transforms.hip: k_fwht_seg / k_fwht_cross)
+template <bool FORWARD>
+static void launch_fwht_big(rspt_hip_packer* p, uint32_t B, hipStream_t st) {
+    const Geom& g = p->g;
+    const uint32_t segs = g.ns >> 15;  // 32768-point pieces per row: 4 .. 128
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht_seg), hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * 4);
+    hipLaunchKernelGGL(k_fwht_seg, dim3(segs, g.nch, B), dim3(1024), 32768 * 4, st, p->planar, g);
+    const uint32_t m1 = segs > 64u ? 64u : segs, m2 = segs / m1;
+    hipLaunchKernelGGL((k_fwht_cross<FORWARD>), dim3(g.ns / m1 / 256u, g.nch, B), dim3(256), 0, st, p->planar, g, p->means, p->mean_i32, m1, 32768u,
+                       m2 == 1u ? 1u : 0u);
+    if (m2 > 1u)
+        hipLaunchKernelGGL((k_fwht_cross<FORWARD>), dim3(g.ns / m2 / 256u, g.nch, B), dim3(256), 0, st, p->planar, g, p->means, p->mean_i32, m2,
+                           32768u * m1, 1u);
+}
+
 template <int BPS>
 static void launch_fixup(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, uint32_t np, hipStream_t st) {
     launch_planes<BPS, true>(p, d_src, nblocks, np, 4 - np, p->nbuse, st);
@@ -596,7 +611,7 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
         }
         p->Tn_native = T;
     }
-    if (kind == RSPT_HIP_KIND_HADAMARD && ns > 65536) {  // one workgroup transforms one channel in LDS
+    if (kind == RSPT_HIP_KIND_HADAMARD && ns > (1u << 22)) {  // (up to 65536 one workgroup per channel; beyond, two passes: launch_fwht_big)
         delete p;
         return RSPT_HIP_ERR_UNSUPPORTED;
     }
@@ -831,6 +846,7 @@ int rspt_hip_reserve(rspt_hip_packer* p, size_t max_blocks) {
     if (g.ns % kRowTile == 0 && g.bps == 4) ok &= hipMalloc(&p->rowrec, max_blocks * (g.N / kRowTile) * (size_t)kRowRec * sizeof(uint32_t)) == hipSuccess;
     ok &= hipMalloc(&p->blk_off, nhb * sizeof(uint64_t)) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT) ok &= hipMalloc(&p->planar2, max_blocks * (size_t)g.N * sizeof(int32_t) + 4096) == hipSuccess;
+    if (g.kind == RSPT_HIP_KIND_HADAMARD && g.ns > 65536u) ok &= hipMalloc(&p->mean_i32, max_blocks * (size_t)g.nch * sizeof(int32_t)) == hipSuccess;
     if (g.kind == RSPT_HIP_KIND_DCT && p->dct_fft) {
         const size_t per_block = (size_t)g.N * sizeof(double2);
         p->fft_bpp = std::max<size_t>(1, std::min<size_t>(max_blocks, ((size_t)1 << 30) / per_block));
@@ -896,7 +912,11 @@ static int phase_front(rspt_hip_packer* p, const uint8_t* src, size_t nblocks, h
     if (g.kind == RSPT_HIP_KIND_HADAMARD) {
         // per channel: mean removal, WHT, truncating /n (signal_packer_hadamard.cpp:57-72)
         const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
-        if (g.ns == 65536u) {  // the whole row in registers: read once, and the byte planes written straight from them
+        if (g.ns > 65536u) {  // two passes over the planar row (any 2^k the reference's own transform takes, fwht.c:4-28)
+            hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
+            launch_fwht_big<true>(p, B, st);
+            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
+        } else if (g.ns == 65536u) {  // the whole row in registers: read once, and the byte planes written straight from them
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
             hipLaunchKernelGGL((k_fwht64k<true, true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means, p->planes, p->nzflag, 3u);
         } else {
@@ -1652,7 +1672,9 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
         const int32_t* final_planar = p->planar;
         if (g.kind == RSPT_HIP_KIND_HADAMARD) {
             const uint32_t fw_lds = (g.ns > 32768u ? 32768u : g.ns) * 4u;
-            if (g.ns == 65536u) {
+            if (g.ns > 65536u) {
+                launch_fwht_big<false>(p, B, st);
+            } else if (g.ns == 65536u) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
                 hipLaunchKernelGGL((k_fwht64k<false, false>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means, (uint8_t*)nullptr,
                                    (uint32_t*)nullptr, 0u);

@@ -147,6 +147,105 @@ __global__ __launch_bounds__(1024) void k_fwht(int32_t* __restrict__ planar, Geo
     }
 }
 
+// ---- rows longer than 65536 points (fwht.c:4-28 transforms any n = 2^k): two passes over the planar row ------------------------
+// WHT_n = WHT_{n / 32768} (x) WHT_32768 -- the stages act on one index bit each and commute exactly in wrap-around arithmetic.
+//   k_fwht_seg    the low 15 index bits: every contiguous 32768-point piece of the row through LDS, in place, nothing else
+//   k_fwht_cross  the high bits: thread <-> column j of the [n / 32768][32768] view, its m <= 64 values (stride `stride` points)
+//                 in registers, butterflies, and -- on the last pass -- what k_fwht does at the end: forward WHT(x - mean) =
+//                 WHT(x) - mean * n * delta_0 and the truncating division by n (fwht.c:30-34), inverse + mean.
+//                 n = 2^22 takes two cross passes (64 x 2).
+__global__ __launch_bounds__(1024) void k_fwht_seg(int32_t* __restrict__ planar, Geom g) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sh[];
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t hn = 32768u;
+    int32_t* seg = planar + (size_t)blockIdx.z * g.N + (size_t)blockIdx.y * g.ns + (size_t)blockIdx.x * hn;
+    for (uint32_t i = tid; i < hn / 4; i += 1024) reinterpret_cast<int4*>(sh)[i] = reinterpret_cast<const int4*>(seg)[i];
+    __syncthreads();
+    uint32_t w = hn >> 1;
+    while (w >= 4) {  // three stages at a time on eight values in registers (as in k_fwht)
+        const uint32_t st = w >> 2;
+        for (uint32_t q = tid; q < (hn >> 3); q += 1024) {
+            const uint32_t base = ((q & ~(st - 1)) << 3) | (q & (st - 1));
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = (uint32_t)sh[base + i * st];
+#pragma unroll
+            for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (!(i & d)) {
+                        const uint32_t x = v[i], y = v[i + d];
+                        v[i] = x + y;
+                        v[i + d] = x - y;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sh[base + i * st] = (int32_t)v[i];
+        }
+        __syncthreads();
+        w >>= 3;
+    }
+    // (15 stages = five rounds of three: none left over)
+    for (uint32_t i = tid; i < hn / 4; i += 1024) reinterpret_cast<int4*>(seg)[i] = reinterpret_cast<const int4*>(sh)[i];
+}
+
+template <bool FORWARD, int M>
+__device__ __forceinline__ void fwht_cross_body(int32_t* __restrict__ row, uint32_t col, uint32_t stride, uint32_t group_span, bool last, uint32_t n,
+                                                int32_t mean) {
+    // the M values of this column: row[base + i * stride], base = (col / stride) * group_span + col % stride
+    const uint32_t base = (col / stride) * group_span + (col % stride);
+    uint32_t v[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) v[i] = (uint32_t)row[base + (size_t)i * stride];
+#pragma unroll
+    for (int d = M / 2; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (!(i & d)) {
+                const uint32_t x = v[i], y = v[i + d];
+                v[i] = x + y;
+                v[i + d] = x - y;
+            }
+        }
+    }
+    const uint32_t k = 31u - (uint32_t)__builtin_clz(n);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        int32_t y = (int32_t)v[i];
+        if (last) {
+            if (FORWARD) {
+                if (base + (size_t)i * stride == 0) y = (int32_t)((uint32_t)y - (uint32_t)mean * n);  // WHT(x - m) = WHT(x) - m*n*delta_0 (mod 2^32)
+                y = (y + ((y >> 31) & (int32_t)(n - 1))) >> k;                                          // truncation toward zero (fwht.c:30-34)
+            } else {
+                y = (int32_t)((uint32_t)y + (uint32_t)mean);
+            }
+        }
+        row[base + (size_t)i * stride] = y;
+    }
+}
+
+// grid (n / m / 256, nch, blocks); m = values per column of this pass, `stride` = their distance in points
+// the mean: forward all 32 bits of it (mean_i32, k_row_means: the subtraction uses them all, hadamard.cpp:62-66), inverse the 24
+// bits the header kept (hadamard.cpp:98-99)
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_fwht_cross(int32_t* __restrict__ planar, Geom g, const uint8_t* __restrict__ means,
+                                                   const int32_t* __restrict__ mean_i32, uint32_t m, uint32_t stride, uint32_t last) {
+    const uint32_t c = blockIdx.y, b = blockIdx.z, n = g.ns;
+    int32_t* row = planar + (size_t)b * g.N + (size_t)c * n;
+    const uint32_t col = blockIdx.x * 256u + threadIdx.x;  // < n / m
+    const int32_t mean = !last ? 0 : FORWARD ? mean_i32[(size_t)b * g.nch + c] : load_mean_hdr(means, g, b, c);
+    const uint32_t span = stride * m;
+    switch (m) {
+        case 2: fwht_cross_body<FORWARD, 2>(row, col, stride, span, last != 0, n, mean); break;
+        case 4: fwht_cross_body<FORWARD, 4>(row, col, stride, span, last != 0, n, mean); break;
+        case 8: fwht_cross_body<FORWARD, 8>(row, col, stride, span, last != 0, n, mean); break;
+        case 16: fwht_cross_body<FORWARD, 16>(row, col, stride, span, last != 0, n, mean); break;
+        case 32: fwht_cross_body<FORWARD, 32>(row, col, stride, span, last != 0, n, mean); break;
+        default: fwht_cross_body<FORWARD, 64>(row, col, stride, span, last != 0, n, mean); break;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // dense DCT-II / inverse, reference arithmetic.  thread <-> output index,
 // CH channels per workgroup share every table load.
@@ -807,6 +906,8 @@ template __global__ void k_dctfft_rows<false>(const double2*, Geom, const uint8_
                                               uint32_t, double, double);
 
 template __global__ void k_fwht<true>(int32_t*, Geom, uint8_t*);
+template __global__ void k_fwht_cross<true>(int32_t*, Geom, const uint8_t*, const int32_t*, uint32_t, uint32_t, uint32_t);
+template __global__ void k_fwht_cross<false>(int32_t*, Geom, const uint8_t*, const int32_t*, uint32_t, uint32_t, uint32_t);
 template __global__ void k_fwht<false>(int32_t*, Geom, uint8_t*);
 template __global__ void k_fwht64k<true, true>(int32_t*, Geom, uint8_t*, uint8_t*, uint32_t*, uint32_t);
 template __global__ void k_fwht64k<false, false>(int32_t*, Geom, uint8_t*, uint8_t*, uint32_t*, uint32_t);

@@ -207,6 +207,27 @@ def dct_big_cases():
                  data=np.ascontiguousarray(synth.synth_native(1, 32768, block_index=13, ecg=True).numpy().reshape(-1)))]
 
 
+def hadamard_big_cases():
+    """hadamard beyond one workgroup's reach (ns = 2^k > 65536): the reference's transform takes any power of two (fwht.c:4-28;
+    its stack arrays need `ulimit -s unlimited`), the GPU build goes through two passes over the planar row.  Amplitudes are
+    kept small enough that |x - mean| * n stays inside int32 (the reference's own precondition for defined behaviour)."""
+    def wave(nch, ns, amp, seed, bps):
+        rng = np.random.default_rng(seed)
+        t = np.arange(ns, dtype=np.float64)[:, None]
+        x = amp * np.sin(t / (97.0 + 13.0 * np.arange(nch)[None, :])) + rng.integers(-8, 8, size=(ns, nch))
+        x = np.round(x).astype(np.int32) + (np.arange(nch, dtype=np.int32)[None, :] * 37 - 50)  # a mean per channel, some negative
+        if bps == 4:
+            return np.ascontiguousarray(x).view(np.uint8).reshape(-1)
+        if bps == 2:
+            return np.ascontiguousarray(x.astype(np.int16)).view(np.uint8).reshape(-1)
+        b = np.ascontiguousarray(x).view(np.uint8).reshape(ns * nch, 4)[:, :bps]
+        return np.ascontiguousarray(b).reshape(-1)
+
+    return [dict(name="wave2x131072_hadamard", kind="hadamard", bps=4, nch=2, ns=131072, nb=3, data=wave(2, 131072, 3000.0, 71, 4)),
+            dict(name="wave3x262144_i24_hadamard", kind="hadamard", bps=3, nch=3, ns=262144, nb=3, data=wave(3, 262144, 900.0, 72, 3)),
+            dict(name="wave1x4194304_i16_hadamard", kind="hadamard", bps=2, nch=1, ns=4194304, nb=3, data=wave(1, 4194304, 150.0, 73, 2))]
+
+
 def dct_dense_big_cases():
     """dct at ns > 8192 that is NOT a power of two: the reference's own n x n table on the GPU as well (bit-exact), up to the
     reach of the reference's int table index (ns <= 32768).  The reference's full stream is the fixture."""

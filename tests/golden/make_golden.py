@@ -102,6 +102,19 @@ def main():
         }
         print("%-28s %-10s size %8d prdn %s" % (c["name"], c["kind"], len(s), out["dct_dense_big"][c["name"]]["prdn"]))
         pk.close()
+    out["hadamard_big"] = {}
+    for c in cases.hadamard_big_cases():  # (needs `ulimit -s unlimited`: fwht.c keeps two n-point arrays on the stack)
+        pk = ref.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+        s = pk.compress(c["data"])
+        dec, used, rc = pk.decompress(s)
+        assert used == len(s) and rc == 0
+        out["hadamard_big"][c["name"]] = {
+            "kind": c["kind"], "bps": c["bps"], "nch": c["nch"], "ns": c["ns"], "nb": c["nb"],
+            "in_crc32": zlib.crc32(c["data"].tobytes()), "size": len(s), "fnv1a": orc.fnv1a(s), "crc32": zlib.crc32(s),
+            "decoded_crc32": zlib.crc32(dec), "prdn": orc.prdn(c["data"], dec, c["ns"], c["nch"], c["bps"]),
+        }
+        print("%-28s %-10s size %8d prdn %s" % (c["name"], c["kind"], len(s), out["hadamard_big"][c["name"]]["prdn"]))
+        pk.close()
     out["iir"] = {}
     for c in cases.iir_cases():
         filt = ref.iir_prefilter(c["data"], c["bps"], c["nch"], c["ns"], c["n"], c["d"], c["init"])

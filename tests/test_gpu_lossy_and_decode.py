@@ -337,3 +337,20 @@ def test_decompress_straight_from_a_container(api, orc):
     assert other.nb == 1  # the handle's own state is neither used nor changed
     pk.close()
     other.close()
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in cases.hadamard_big_cases()])
+def test_hadamard_beyond_65536_points(api, orc, golden, name):
+    """ns = 2^k > 65536 (two passes over the planar row: k_fwht_seg + k_fwht_cross; 2^22 takes two cross passes): the stream and
+    the decoded block are the real reference's (fixtures from oracle/_ref), for int32 / int24 / int16 samples"""
+    import zlib
+
+    c = {x["name"]: x for x in cases.hadamard_big_cases()}[name]
+    g = golden["hadamard_big"][name]
+    pk = api.new_hadamard(c["bps"], c["nch"], c["ns"])
+    got = pk.compress(c["data"])
+    assert len(got) == g["size"] and orc.fnv1a(got) == g["fnv1a"] and zlib.crc32(got) == g["crc32"]
+    dec = pk.decompress(got)
+    dec = dec[0] if isinstance(dec, tuple) else dec
+    assert zlib.crc32(bytes(dec)) == g["decoded_crc32"]
+    pk.close()

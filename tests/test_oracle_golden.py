@@ -102,3 +102,17 @@ def test_nb_state_persists_across_calls(orc):
         pos += 4 + struct.unpack_from("<I", s_small_after, pos)[0]
         k += 1
     assert k == nb and pos == len(s_small_after)
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in cases.hadamard_big_cases()])
+def test_hadamard_beyond_65536_points_golden(orc, golden, name):
+    """ns = 2^k > 65536: the restatement against the real reference's stream and decoded block (fwht.c:4-28 takes any 2^k)"""
+    c = {x["name"]: x for x in cases.hadamard_big_cases()}[name]
+    g = golden["hadamard_big"][name]
+    assert zlib.crc32(c["data"].tobytes()) == g["in_crc32"], "test input drifted"
+    pk = orc.packer(c["kind"], c["bps"], c["nch"], c["ns"], c["nb"])
+    s = pk.compress(c["data"])
+    assert len(s) == g["size"] and orc.fnv1a(s) == g["fnv1a"] and zlib.crc32(s) == g["crc32"]
+    dec, used, rc = pk.decompress(s)
+    assert rc == 0 and used == len(s) and zlib.crc32(dec) == g["decoded_crc32"]
+    pk.close()
