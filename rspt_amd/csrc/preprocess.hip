@@ -144,10 +144,12 @@ struct TileCtx {
     uint8_t* out;      // LDS rows [plane][channel][RS]
     uint32_t* s_nz;    // LDS dedupe masks [rel][plane][channel]
     uint32_t* nzflag;  // HBM non-zero map
+    uint8_t* gplanes;  // (timing probe, diagnostic builds: plane bytes straight from the registers to HBM)
+    uint32_t dirty_shift;
 };
 
 // item q, its 18 samples in R: transform, plane split into the LDS rows, non-zero map, escalation magnitude
-template <int BPS, bool XDELTA>
+template <int BPS, bool XDELTA, bool DIRECT = false>
 __device__ __forceinline__ void transform_item(const ItemRegs& R, uint32_t q, const TileCtx& tc, uint32_t& mag, uint32_t& nz_seg,
                                                uint32_t& nz_done) {
     const Geom& g = tc.g;
@@ -219,8 +221,18 @@ __device__ __forceinline__ void transform_item(const ItemRegs& R, uint32_t q, co
     uint32_t nzm = 0;  // bit k: plane k of this item holds a non-zero byte
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-        if (k >= kfirst && k < kfirst + kcount)
-            *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+        if (k >= kfirst && k < kfirst + kcount) {
+            if (DIRECT && (ablate & (1u << 26))) {  // timing probe: no LDS rows, 16-byte stores from the registers (all-zero units of clean blocks skipped)
+                const bool nz = (pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0;
+                const uint32_t bucket = ((c * g.ns + s0 + t0) >> 16) >> tc.dirty_shift;
+                const bool dirty = (s_nz[8 * g.nch + 1 + (k - kfirst) * 4 + (bucket >> 5)] >> (bucket & 31u)) & 1u;
+                if (nz || dirty)
+                    *reinterpret_cast<uint4*>(tc.gplanes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)c * g.ns + s0 + t0) =
+                        make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+            } else {
+                *reinterpret_cast<uint4*>(out + (size_t)((k - kfirst) * g.nch + c) * RS + t0) = make_uint4(pw[k][0], pw[k][1], pw[k][2], pw[k][3]);
+            }
+        }
         nzm |= ((pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0 ? 1u : 0u) << k;
     }
     // Non-zero map.  A thread mostly walks along one channel, and a tile row spans at most two 4 KiB segments: the
@@ -598,7 +610,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
     const uint32_t RS = T + 16;  // out row stride (bytes): rows stay 16-aligned, banks rotate per row
     uint8_t* out = lds;
     uint32_t* s_nz = reinterpret_cast<uint32_t*>(out + (size_t)kcount * g.nch * RS);
-    TileCtx tc{g, m_nch, 0, 0, 0, kfirst, kcount, RS, RSPT_DIAG_ONLY(ablate), fixup, out, s_nz, nzflag};
+    TileCtx tc{g, m_nch, 0, 0, 0, kfirst, kcount, RS, RSPT_DIAG_ONLY(ablate), fixup, out, s_nz, nzflag, planes, dirty_shift};
     auto t_open = [&]() {
         tc.b = tw / tiles_per_block;
         tc.s0 = tile_s0(tw);
@@ -647,7 +659,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             const uint32_t c = row - kr * g.nch;
             const uint8_t* sp = out + (size_t)row * RS + colu * 16;
             uint8_t* dp = planes + ((size_t)tc.b * kMaxPlanes + kfirst + kr) * g.plane_stride + (size_t)c * g.ns + tc.s0 + colu * 16;
-            if (RSPT_DIAG_ONLY(ablate) & 16384u) continue;  // timing probe: no stores (diagnostic builds only)
+            if (RSPT_DIAG_ONLY(ablate) & (16384u | (1u << 26))) continue;  // timing probes: no stores / stores straight from the registers (diagnostic builds only)
             const uint4 v = *reinterpret_cast<const uint4*>(sp);
             // a clean hzr block (zeros everywhere, see rspt_hip_packer::plane_dirty) only takes the 128-byte lines that hold
             // a non-zero byte: a line is eight consecutive units = eight aligned lanes (T is a multiple of 128)
@@ -681,7 +693,11 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
         if (q < t_nitems) {
             if (BPS == 3) stream_fix24<RAGGED>(R, g, m_nch, tc.s0, tc.Tn, lim4_of(tc.b), tc.b + 1 == nblocks && tc.s0 + tc.Tn == g.ns, q);
             if (BPS != 3 && g.be) stream_swap<BPS>(R);  // (wave-uniform; the registers have landed: nothing of this set is in flight here)
+#ifdef RSPT_DIAG
+            transform_item<BPS, XDELTA, (BPS == 4 && XDELTA && !RAGGED)>(R, q, tc, mag, nz_seg, nz_done);
+#else
             transform_item<BPS, XDELTA>(R, q, tc, mag, nz_seg, nz_done);
+#endif
         }
         fetch(R);  // (ahead of this tile's stores: a load queued behind them would wait for their acknowledgements)
         if (++tj == t_ipt) {
