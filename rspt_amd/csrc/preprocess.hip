@@ -419,11 +419,14 @@ __global__ __launch_bounds__(1024) void k_tile_planes(const uint8_t* __restrict_
 // (tools/check_stream_regs.py checks the generated code for exactly that).  A stream that has run out of tiles keeps
 // loading item 0 of block 0; lanes past a tile's item count load its last item and skip the transform.
 // One sample per load for every width: int32 -> dword; int24 -> an UNALIGNED dword at the sample's first byte (the hardware
-// takes it; the byte behind the sample comes along and is shifted out after the wait), int16 -> a sign-extending short.
+// takes it; the byte behind the sample comes along and is shifted out after the wait), int16 -> a sign-extending short, int8 -> a
+// sign-extending byte (utils.cpp:186-189).
 template <int BPS>
 __device__ __forceinline__ uint32_t stream_load(const uint8_t* base, uint32_t off) {
     uint32_t v;
-    if (BPS == 2)
+    if (BPS == 1)
+        asm volatile("global_load_sbyte %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
+    else if (BPS == 2)
         asm volatile("global_load_sshort %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
     else
         asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(off), "s"(base));
@@ -510,6 +513,7 @@ __device__ __forceinline__ void stream_fix24(ItemRegs& R, const Geom& g, uint32_
 // int32 / int16 big-endian samples: byte reversal of the landed registers (int16: the load sign-extended the wrong byte)
 template <int BPS>
 __device__ __forceinline__ void stream_swap(ItemRegs& R) {
+    if (BPS == 1) return;  // (one byte has no order)
     auto sw = [](uint32_t v) -> uint32_t {
         if (BPS == 4) return __builtin_amdgcn_perm(v, v, 0x00010203u);
         return (uint32_t)((int32_t)(__builtin_amdgcn_perm(v, v, 0x00010001u) << 16) >> 16);  // bytes 0 and 1 swapped, then sign-extended from 16 bits
@@ -974,6 +978,10 @@ INST_TILE(1)
 INST_TILE(2)
 INST_TILE(3)
 INST_TILE(4)
+template __global__ void k_tile_stream<1, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<1, true, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<1, false, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
+template __global__ void k_tile_stream<1, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_tile_stream<2, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_tile_stream<3, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_tile_stream<4, true, false>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);

@@ -253,11 +253,10 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
     uint32_t want = per_cu * (uint32_t)p->num_cu;
     if (p->k1_grid) want = p->k1_grid;
     dim3 grid(want < ntiles ? want : ntiles);
-    // int32 / int24 / int16 input streams (k_tile_stream, one load per sample); int8 takes the general kernel
-    const bool stream = BPS >= 2 && (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && g.ns >= 16 && g.block_bytes < (1ull << 32) &&
-                        !(p->ablate & (1u << 22));
+    // every sample width streams (k_tile_stream, one load per sample: dword / unaligned dword / short / byte)
+    const bool stream = (reinterpret_cast<uintptr_t>(d_src) & 3u) == 0 && g.ns >= 16 && g.block_bytes < (1ull << 32) && !(p->ablate & (1u << 22));
     if (stream) {
-        constexpr int SB = BPS >= 2 ? BPS : 4;  // (never instantiated for int8)
+        constexpr int SB = BPS;
         auto go = [&](auto kern) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d_src, g, T, kfirst, kcount, p->planes, p->needmask, p->nzflag, nbuse, p->ablate,

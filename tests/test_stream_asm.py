@@ -36,9 +36,9 @@ def test_no_register_is_touched_between_a_hand_issued_load_and_its_wait(device_a
             name, rest = line.split(":", 1)
             states, bad = [int(t) for t in rest.replace(",", " ").split() if t.isdigit()]
             summary[name.strip()] = (states, bad)
-    # every instantiation (int32 / int24 / int16, xdelta and plain, whole and ragged tiles) was found, its control-flow graph
+    # every instantiation (int32 / int24 / int16 / int8, xdelta and plain, whole and ragged tiles) was found, its control-flow graph
     # was walked (hundreds of ring states each) and no instruction touches a register with a hand-issued load in flight
-    assert len(summary) == 12, summary
+    assert len(summary) == 16, summary
     assert all(v[0] >= 300 for v in summary.values()), summary
     for name, (states, bad) in summary.items():
         assert bad == 0, (name, bad, out[-3000:])

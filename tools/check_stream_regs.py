@@ -65,7 +65,7 @@ def check_cfg(lines, name):
         succ = None
         for ln, code, in_asm in blocks[bi]["ins"]:
             if in_asm:
-                m = re.match(r"global_load_(?:dword|sshort) v(\d+),", code)
+                m = re.match(r"global_load_(?:dword|sshort|sbyte) v(\d+),", code)
                 if m: pend.append(int(m.group(1))); continue
                 m = re.match(r"s_load_dwordx4 s\[(\d+):(\d+)\],", code)
                 if m: spend |= set(range(int(m.group(1)), int(m.group(2)) + 1)); continue
