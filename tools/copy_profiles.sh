@@ -7,4 +7,4 @@ cp $P/kernel_stats.csv profiles/${R}_kernel_stats.csv
 cp $P/dec_kernel_stats.csv profiles/${R}_dec_kernel_stats.csv
 cp $P/pmc_issue.txt profiles/${R}_pmc_issue.txt
 cp $P/host_api_rate.txt profiles/${R}_host_api_rate.txt
-for x in a b c; do cp gpurun_out/pmcw/pmc_wait_$x.txt profiles/${R}_pmc_wait_$x.txt; done
+for x in a b c; do [ -f gpurun_out/pmcw/pmc_wait_$x.txt ] && cp gpurun_out/pmcw/pmc_wait_$x.txt profiles/${R}_pmc_wait_$x.txt; done; true
