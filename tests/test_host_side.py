@@ -345,3 +345,35 @@ def test_feed_equals_a_loop_of_compress_calls(api, orc, group, slots, pinned):
     pk.close()
     for b in bufs:
         b.close()
+
+
+@pytest.mark.gpu
+def test_batch_entry_points_refuse_while_a_feed_is_open(api):
+    """the feed owns the handle's plane workspace and copy streams: batch / many-block calls in between return RSPT_HIP_ERR_ARG
+    (they used to run and race the feed's launches), and the handle is an ordinary packer again after rspt_hip_feed_end"""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns, B = 8, 2048, 3
+    pk = api.new_xdelta_hzr(4, nch, ns, 2)
+    d_src = synth.synth_batch_native(B, nch, ns, device="cuda")
+    want_dst, want_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    pk.feed_begin(2, 2)
+    with pytest.raises(api.RsptHipError) as e:
+        pk.compress_batch(d_src)
+    assert e.value.status == -1
+    with pytest.raises(api.RsptHipError):
+        pk.decompress_batch(want_dst, B, want_dst.shape[1])
+    host = d_src.cpu().numpy()
+    out = np.zeros((B, pk.max_compressed_size), dtype=np.uint8)
+    with pytest.raises(api.RsptHipError):
+        pk.compress_many(host, out)
+    pk.feed_end()
+    got_dst, got_sizes = pk.compress_batch(d_src)
+    torch.cuda.synchronize()
+    assert torch.equal(got_sizes, want_sizes)
+    for b in range(B):
+        assert torch.equal(got_dst[b, : int(got_sizes[b])], want_dst[b, : int(want_sizes[b])])
+    pk.close()
