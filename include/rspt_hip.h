@@ -109,8 +109,10 @@ int rspt_hip_set_verify(rspt_hip_packer* p, int on);
  * byte-reversed (little-endian) block. */
 int rspt_hip_set_byte_order(rspt_hip_packer* p, int big_endian);
 
-/* Page-locked host memory for the host-pointer entry points: with src / dst in such buffers rspt_hip_compress and
- * rspt_hip_decompress move their data by DMA at link rate instead of through the runtime's pageable staging copies
+/* Page-locked host memory for the host-pointer entry points: with src / dst in such buffers (16-byte aligned source)
+ * rspt_hip_compress has no copy phases at all -- the front end reads the samples across the link as it transforms them and the
+ * encoders write the stream into the caller's buffer -- and rspt_hip_decompress writes the samples there from its last kernel;
+ * the many-block forms move their data by DMA at link rate instead of through the runtime's pageable staging copies
  * (the acquisition front end of the reference, lib_ring_buffer/ring_buffers.h:150-203 io_buffer, would allocate its
  * slots here).  NULL on failure. */
 void* rspt_hip_host_alloc(size_t bytes);

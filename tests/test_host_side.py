@@ -377,3 +377,47 @@ def test_batch_entry_points_refuse_while_a_feed_is_open(api):
     for b in range(B):
         assert torch.equal(got_dst[b, : int(got_sizes[b])], want_dst[b, : int(want_sizes[b])])
     pk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,bps,nch,ns", [("xdelta_hzr", 4, 64, 65536), ("xdelta_hzr", 3, 5, 20003), ("hzr", 2, 7, 1001),
+                                             ("hadamard", 4, 12, 16384), ("dct", 4, 3, 4096), ("xdelta_hzr", 1, 3, 5000)])
+def test_page_locked_buffers_are_used_in_place(api, orc, kind, bps, nch, ns):
+    """With page-locked source / destination buffers rspt_hip_compress reads the samples across the link from the front end and
+    the encoders write the stream into the caller's buffer; rspt_hip_decompress writes the samples there (no copy phases).  Same
+    bytes as through the staged path -- for every packer, aligned and unaligned views (an unaligned source is staged), a
+    destination that is too small (nothing written, the needed size reported), and escalation across calls."""
+    from rspt_amd import synth
+
+    x = synth.synth_native(nch, ns, block_index=21, bps=bps, ecg=True).numpy().reshape(-1)
+    po = orc.packer(kind, bps, nch, ns, 2)
+    pk = api.SignalPacker(kind, bps, nch, ns, 2)
+    ref = api.SignalPacker(kind, bps, nch, ns, 2)  # the staged path: pageable buffers
+    cap = pk.max_compressed_size
+    src, dst, back = api.HostBuffer(x.size + 64), api.HostBuffer(cap + 64), api.HostBuffer(x.size + 64)
+    for off in (0, 16, 5):  # (5: not 16-byte aligned -> staged; the destination may sit anywhere)
+        s_view, d_view, b_view = src.a[off : off + x.size], dst.a[off : off + cap], back.a[off : off + x.size]
+        s_view[:] = x
+        d_view[:] = 0xEE
+        n = pk.compress_into(s_view, d_view)
+        want = ref.compress(x.copy())
+        assert d_view[:n].tobytes() == want, (off, n, len(want))
+        assert (d_view[n:] == 0xEE).all()  # nothing behind the stream was touched
+        if kind in ("xdelta_hzr", "hzr"):
+            assert want == po.compress(x)
+        b_view[:] = 0
+        used = pk.decompress_into(d_view, b_view)
+        rb, ru = ref.decompress(want)
+        assert used == n == ru and b_view.tobytes() == rb
+    # too small (40 bytes: staged; 128 bytes: in place, the kernels are given exactly that much): reported, nothing written
+    src.a[: x.size] = x
+    for room in (40, 128):
+        tiny = dst.a[:room]
+        tiny[:] = 0x55
+        with pytest.raises(api.RsptHipError) as e:
+            pk.compress_into(src.a[: x.size], tiny)
+        assert e.value.status == -5 and (tiny == 0x55).all(), room
+    for b in (src, dst, back):
+        b.close()
+    pk.close()
+    ref.close()
