@@ -222,7 +222,7 @@ __device__ __forceinline__ void transform_item(const ItemRegs& R, uint32_t q, co
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         if (k >= kfirst && k < kfirst + kcount) {
-            if (DIRECT && (ablate & (1u << 26))) {  // timing probe: no LDS rows, 16-byte stores from the registers (all-zero units of clean blocks skipped)
+            if (DIRECT && ((ablate & (1u << 26)) || ((ablate & (1u << 27)) && k >= 1))) {  // timing probes: no LDS rows, 16-byte stores from the registers, all-zero units of clean blocks skipped (bit 27: the planes above 0 only)
                 const bool nz = (pw[k][0] | pw[k][1] | pw[k][2] | pw[k][3]) != 0;
                 const uint32_t bucket = ((c * g.ns + s0 + t0) >> 16) >> tc.dirty_shift;
                 const bool dirty = (s_nz[8 * g.nch + 1 + (k - kfirst) * 4 + (bucket >> 5)] >> (bucket & 31u)) & 1u;
@@ -664,6 +664,7 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
             const uint8_t* sp = out + (size_t)row * RS + colu * 16;
             uint8_t* dp = planes + ((size_t)tc.b * kMaxPlanes + kfirst + kr) * g.plane_stride + (size_t)c * g.ns + tc.s0 + colu * 16;
             if (RSPT_DIAG_ONLY(ablate) & (16384u | (1u << 26))) continue;  // timing probes: no stores / stores straight from the registers (diagnostic builds only)
+            if ((RSPT_DIAG_ONLY(ablate) & (1u << 27)) && kr >= 1) continue;
             const uint4 v = *reinterpret_cast<const uint4*>(sp);
             // a clean hzr block (zeros everywhere, see rspt_hip_packer::plane_dirty) only takes the 128-byte lines that hold
             // a non-zero byte: a line is eight consecutive units = eight aligned lanes (T is a multiple of 128)

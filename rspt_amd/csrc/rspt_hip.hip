@@ -897,7 +897,7 @@ static int phase_front(rspt_hip_packer* p, const uint8_t* src, size_t nblocks, h
         if (!p->zero_ready[p->zset]) HIPCHK(p, hipMemsetAsync(p->nzflag, 0, zwords * sizeof(uint32_t), st));  // (first call, or after a failed one)
         p->zero_ready[0] = p->zero_ready[1] = false;  // this copy is in use now; the other one becomes ready once k_tree is launched
     }
-    if (p->planes_unknown || (p->ablate & ~(1u << 26)) || p->psel) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave; probe 26 stores everything)
+    if (p->planes_unknown || (p->ablate & ~(3u << 26)) || p->psel) {  // (diagnostic runs skip kernels and stores: never trust the planes they leave; probes 26 / 27 store everything)
         HIPCHK(p, hipMemsetAsync(p->plane_dirty, 0xFF, p->cap_blocks * kMaxPlanes * 4 * sizeof(uint32_t), st));
         p->planes_unknown = false;
     }
