@@ -44,6 +44,9 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
     ap.add_argument("--blocks", type=int, default=None, help="c3: blocks per GPU per step (default 64); c5: total blocks (default 1024)")
+    ap.add_argument("--slots", type=int, default=1, help="c5 only: steps in flight per rank, each on its own handle (its own plane workspace, the "
+                    "reference's one packer object per worker) and stream, taken round-robin; small shards leave most of the GPU idle inside "
+                    "every kernel of a step (DESIGN 6b)")
     ap.add_argument("--nch", type=int, default=None)
     ap.add_argument("--ns", type=int, default=None)
     ap.add_argument("--nb", type=int, default=3)
@@ -299,6 +302,12 @@ def main():
     if args.op == "prefilter":
         sys.exit(bench_prefilter(args))
 
+    if args.slots > 1:
+        # The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
+        # share a queue run one after the other: with 2 slots (4 streams of the handles + torch's) the two steps in flight landed
+        # on one queue and nothing overlapped (128-block shard: 0.163 ms per step; 0.115 with 8 queues -- profiles/r04_notes.md 3).
+        # Read by the runtime when it initialises, i.e. before anything here touches the GPU.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 2 * args.slots)))
     import torch
 
     from rspt_amd import api, shard, synth
@@ -335,21 +344,32 @@ def main():
         B = args.blocks
         first = rank * B
         total_blocks = world * B
-    pk = api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank)
-    pk.reserve(B)
+    S = args.slots
+    if S < 1 or (S > 1 and not (c5 and args.op == "compress")):
+        sys.stderr.write("bench.py: --slots is for --workload c5 compress lines\n")
+        sys.exit(2)
+    pks = [api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank) for _ in range(S)]
+    pk = pks[0]
+    for q in pks:
+        q.reserve(B)
+    nbuf = 2 * S  # every slot alternates between two buffer sets (as its handle alternates between two workspace sets)
     # synthetic input, resident in HBM: TWO distinct batches alternate in the timed loop (the front end's behaviour depends on
     # what the previous call left in the plane workspace); every rank gets different blocks (SURVEY 8d generator)
-    d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(2)]
+    d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(nbuf)]
     if args.big_endian:  # the same samples, bytes reversed; the streams are the little-endian ones (checked below against the oracle)
         d_le = d_src
         d_src = [x.view(B, -1, args.bps).flip(2).contiguous().view(B, -1) for x in d_le]
-        pk.set_byte_order(True)
+        for q in pks:
+            q.set_byte_order(True)
     else:
         d_le = d_src
     dst_stride = (pk.max_compressed_size + 255) // 256 * 256
-    d_dst = [torch.empty((B, dst_stride), dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_sizes = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(2)]
+    d_dst = [torch.empty((B, dst_stride), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    d_sizes = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(nbuf)]
     stream = torch.cuda.current_stream(dev)
+    # several steps in flight: each on its handle's own stream (two streams per handle exist anyway; further ones would share
+    # hardware queues with them -- see GPU_MAX_HW_QUEUES above)
+    slot_streams = [stream] if S == 1 else [torch.cuda.ExternalStream(q.stream_ptr, device=dev) for q in pks]
 
     # gather plan (N>1): each rank packs its streams into a container on the device
     # (rspt_hip_pack_batch_dev) and the containers go to rank 0 over RCCL: sizes by
@@ -359,8 +379,8 @@ def main():
     need_pack = c5 or do_gather
     side = torch.cuda.Stream(dev) if (do_gather and not c5) else None
     bound = pk.pack_bound(B)
-    packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(2)] if need_pack else None
-    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)] if need_pack else None
+    packed = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(nbuf)] if need_pack else None
+    totals = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(nbuf)] if need_pack else None
     recv_bufs = None
     if do_gather and rank == 0:
         recv_bufs = [None] + [torch.empty(pk.pack_bound(shard.shard_range(args.blocks, r, world)[1] if c5 else B), dtype=torch.uint8, device=dev)
@@ -391,13 +411,19 @@ def main():
             pk.decompress_batch(d_dst[slot], B, dst_stride, d_back, d_used)
             return
         if c5:
-            # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step
-            pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
-            if lag is not None:
-                lag.wait_slot_free(slot)  # (the container of two steps ago has left this buffer)
-            pk.pack_batch(d_dst[slot], d_sizes[slot], packed[slot], totals[slot])
-            if lag is not None:
-                lag.step(packed[slot], totals[slot])
+            # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step.  --slots S: step n runs on handle
+            # and stream n % S (no event between the slots: nothing is shared), on buffer set n % 2S
+            n = nstep[0] - 1
+            h, bs = n % S, n % nbuf
+            with torch.cuda.stream(slot_streams[h]):
+                pks[h].compress_batch(d_src[bs], d_dst[bs], d_sizes[bs], dst_stride)
+                if lag is not None:
+                    # the payload group posted a step ago read the container of two steps ago; this buffer set was last used 2S >= 2
+                    # steps ago, and the gather stream runs in order: behind that event its container has left
+                    lag.wait_slot_free(slot)
+                pks[h].pack_batch(d_dst[bs], d_sizes[bs], packed[bs], totals[bs])
+                if lag is not None:
+                    lag.step(packed[bs], totals[bs])
             return
         if slot_free[slot] is not None and not slot_free[slot].query():  # (two steps old: almost always done -- then no barrier packet)
             stream.wait_event(slot_free[slot])
@@ -443,6 +469,20 @@ def main():
 
     if lag is not None:
         gathered_bytes[0] = lag.gathered_bytes
+    # --slots > 1: the same step with ONE step in flight, for the latency beside the throughput (no gather in this leg)
+    single_ms = None
+    if S > 1:
+        torch.cuda.synchronize()
+        with torch.cuda.stream(slot_streams[0]):
+            for rep_ in range(2):
+                if rep_ == 1:
+                    torch.cuda.synchronize()
+                    g0 = time.perf_counter()
+                for i in range(args.steps):
+                    pk.compress_batch(d_src[i & 1], d_dst[i & 1], d_sizes[i & 1], dst_stride)
+                    pk.pack_batch(d_dst[i & 1], d_sizes[i & 1], packed[i & 1], totals[i & 1])
+            torch.cuda.synchronize()
+            single_ms = (time.perf_counter() - g0) / args.steps * 1e3
     # c3, N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
     # could take the output of only 2-3 GPUs at this rate); its time is reported beside the metric
     gather_ms = None
@@ -569,10 +609,13 @@ def main():
             "verified": verified,
             "config": {
                 "workload": ("%s nb=%d, %d blocks in total of %s (BASELINE configs[4]), contiguous shards, container pack + gather to rank 0 "
-                             "inside the step, device-resident" % (args.packer, args.nb, total_blocks, shape)) if c5 else
+                             "inside the step, device-resident%s" % (args.packer, args.nb, total_blocks, shape,
+                                                                "; %d steps in flight per rank, each on its own handle and stream" % S if S > 1 else "")) if c5 else
                             ("%s nb=%d, %d blocks/GPU/step of %s (BASELINE configs[2] shape, xdelta_hzr path), two alternating batches, "
                              "device-resident" % (args.packer, args.nb, B, shape)),
                 "blocks_per_gpu": B,
+                "steps_in_flight": S,
+                "ms_per_step_one_in_flight": round(single_ms, 4) if single_ms is not None else None,
                 "compression_ratio": round(in_bytes / out_bytes, 4),
                 "gather": ("every step, inside the timed region%s" % (" (sizes by device all-gather, payload one step behind: no host sync in the step)" if lag is not None else "")
                            if payload_every_step else "sizes every step, payload once after the timed steps") if do_gather else False,
@@ -614,7 +657,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    pk.close()
+    for q in pks:
+        q.close()
     if rank == 0 and verified is False:
         sys.exit(3)
 

@@ -350,6 +350,13 @@ class SignalPacker:
     def synchronize(self):
         self._check("rspt_hip_synchronize", self._L.rspt_hip_synchronize(self._h))
 
+    @property
+    def stream_ptr(self):
+        """the handle's own hipStream_t (rspt_hip_stream): what the host-pointer entry points run on; a caller with several
+        handles in flight can launch each handle's batches on it (torch.cuda.ExternalStream(pk.stream_ptr)) instead of making
+        further streams -- the runtime maps streams onto few hardware queues (GPU_MAX_HW_QUEUES, default 4)"""
+        return int(self._L.rspt_hip_stream(self._h) or 0)
+
     def debug_read(self, which, nbytes):
         """test hook: workspace buffer `which` of the last batch call (see rspt_hip.h)"""
         out = np.zeros(nbytes, dtype=np.uint8)

@@ -200,7 +200,7 @@ def test_cxx_factories_follow_the_device_setting(api, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["c5", "c3"])
+@pytest.mark.parametrize("workload", ["c5", "c3", "c5-slots2"])
 def test_bench_under_the_launcher_with_one_rank(api, workload):
     """The N > 1 branch of bench.py -- RANK set, init_process_group("nccl"), the side-stream exchange of sizes, the container
     pack + (lagged) gather of --workload c5 -- through RCCL with a world of one rank: the code the driver's 2/4/8-GPU runs take,
@@ -216,6 +216,11 @@ def test_bench_under_the_launcher_with_one_rank(api, workload):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", workload, "--steps", "3", "--warmup", "1", "--no-cpu"]
+    slots = 2 if workload == "c5-slots2" else 1  # two steps in flight on two handles: the small-shard mode
+    if slots > 1:
+        workload = "c5"
+        cmd[cmd.index("c5-slots2")] = "c5"
+        cmd += ["--slots", "2", "--blocks", "128"]
     if workload == "c3":
         cmd += ["--blocks", "4"]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -227,6 +232,7 @@ def test_bench_under_the_launcher_with_one_rank(api, workload):
     assert r["config"]["gather"]  # the exchange ran (a string describing it), not the --no-gather shortcut
     if workload == "c5":
         assert "no host sync" in r["config"]["gather"] and r["config"]["gathered_bytes"] > 0
+        assert r["config"]["steps_in_flight"] == slots and (r["config"]["ms_per_step_one_in_flight"] is not None) == (slots > 1)
 
 
 def _build_gather_example(tmp_path):
@@ -421,3 +427,58 @@ def test_page_locked_buffers_are_used_in_place(api, orc, kind, bps, nch, ns):
         b.close()
     pk.close()
     ref.close()
+
+
+@pytest.mark.gpu
+def test_batch_calls_can_be_captured_into_a_graph(api, orc):
+    """The batch entry points only enqueue work (no host synchronisation, no allocation once rspt_hip_reserve has run), so a host
+    may record a handle's steps into a HIP graph and replay them (small shards): two steps per graph, since a
+    handle alternates between two plane-workspace sets.  The replayed steps give the bytes of the direct calls == the oracle's."""
+    import torch
+
+    from rspt_amd import synth
+
+    nch, ns, B = 12, 8192, 24
+    dev = torch.device("cuda", 0)
+    pk = api.new_xdelta_hzr(4, nch, ns, 3)
+    pk.reserve(B)
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    srcs = [synth.synth_batch_native(B, nch, ns, first_block=s * B, device=dev) for s in range(2)]
+    dst = [torch.zeros((B, stride), dtype=torch.uint8, device=dev) for _ in range(2)]
+    sz = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(2)]
+    cont = [torch.zeros(pk.pack_bound(B), dtype=torch.uint8, device=dev) for _ in range(2)]
+    tot = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
+    st = torch.cuda.ExternalStream(pk.stream_ptr, device=dev)
+    want, want_cont = [], []
+    with torch.cuda.stream(st):
+        for s in range(2):
+            pk.compress_batch(srcs[s], dst[s], sz[s], stride)
+            pk.pack_batch(dst[s], sz[s], cont[s], tot[s])
+    torch.cuda.synchronize()
+    po = orc.packer("xdelta_hzr", 4, nch, ns, 3)
+    for s in range(2):
+        want.append([dst[s][b, : int(sz[s][b])].cpu().numpy().tobytes() for b in range(B)])
+        want_cont.append(cont[s][: int(tot[s])].cpu().numpy().tobytes())
+        assert want[s][0] == po.compress(srcs[s][0].cpu().numpy()) if s == 0 else True
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)  # (the calls go to torch's current stream: the capturing one)
+    with torch.cuda.graph(g, stream=side):
+        for s in range(2):
+            pk.compress_batch(srcs[s], dst[s], sz[s], stride)
+            pk.pack_batch(dst[s], sz[s], cont[s], tot[s])
+    for rep in range(3):
+        for s in range(2):
+            dst[s].zero_(), sz[s].zero_(), cont[s].zero_(), tot[s].zero_()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        for s in range(2):
+            got = [dst[s][b, : int(sz[s][b])].cpu().numpy().tobytes() for b in range(B)]
+            assert got == want[s], (rep, s)
+            assert cont[s][: int(tot[s])].cpu().numpy().tobytes() == want_cont[s], (rep, s)
+    # and the handle goes on with direct calls afterwards
+    with torch.cuda.stream(st):
+        pk.compress_batch(srcs[1], dst[1], sz[1], stride)
+    torch.cuda.synchronize()
+    assert [dst[1][b, : int(sz[1][b])].cpu().numpy().tobytes() for b in range(B)] == want[1]
+    pk.close()
