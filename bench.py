@@ -345,14 +345,14 @@ def main():
         first = rank * B
         total_blocks = world * B
     S = args.slots
-    if S < 1 or (S > 1 and not (c5 and args.op == "compress")):
-        sys.stderr.write("bench.py: --slots is for --workload c5 compress lines\n")
+    if S < 1 or (S > 1 and not ((c5 and args.op == "compress") or (not c5 and args.op == "decompress"))):
+        sys.stderr.write("bench.py: --slots is for --workload c5 compress lines and for --op decompress\n")
         sys.exit(2)
     pks = [api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank) for _ in range(S)]
     pk = pks[0]
     for q in pks:
         q.reserve(B)
-    nbuf = 2 * S  # every slot alternates between two buffer sets (as its handle alternates between two workspace sets)
+    nbuf = 2 * S if c5 else 2  # every slot alternates between two buffer sets (as its handle alternates between two workspace sets)
     # synthetic input, resident in HBM: TWO distinct batches alternate in the timed loop (the front end's behaviour depends on
     # what the previous call left in the plane workspace); every rank gets different blocks (SURVEY 8d generator)
     d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(nbuf)]
@@ -398,8 +398,9 @@ def main():
         for s_ in range(2):
             pk.compress_batch(d_src[s_], d_dst[s_], d_sizes[s_], dst_stride)
         torch.cuda.synchronize()
-        d_back = torch.empty((B, pk.block_bytes), dtype=torch.uint8, device=dev)
-        d_used = torch.empty(B, dtype=torch.int64, device=dev)
+        d_back = [torch.empty((B, pk.block_bytes), dtype=torch.uint8, device=dev) for _ in range(S)]  # (one output per batch in flight)
+        d_used = [torch.empty(B, dtype=torch.int64, device=dev) for _ in range(S)]
+        last_of_slot = [None] * S
 
     nstep = [0]  # steps so far: runs on through warm-up and timed loop, so that the buffer parity never jumps (the lagged gather's own
     #              slot parity is a step counter too)
@@ -408,7 +409,10 @@ def main():
         slot = nstep[0] & 1
         nstep[0] += 1
         if decomp:
-            pk.decompress_batch(d_dst[slot], B, dst_stride, d_back, d_used)
+            h = (nstep[0] - 1) % S  # --slots S: batch n is decoded on handle and stream n % S
+            with torch.cuda.stream(slot_streams[h]):
+                pks[h].decompress_batch(d_dst[slot], B, dst_stride, d_back[h], d_used[h])
+            last_of_slot[h] = slot
             return
         if c5:
             # strong scaling: compress the shard, pack it, gather to rank 0 -- all inside the step.  --slots S: step n runs on handle
@@ -479,6 +483,10 @@ def main():
                     torch.cuda.synchronize()
                     g0 = time.perf_counter()
                 for i in range(args.steps):
+                    if decomp:
+                        pk.decompress_batch(d_dst[i & 1], B, dst_stride, d_back[0], d_used[0])
+                        last_of_slot[0] = i & 1
+                        continue
                     pk.compress_batch(d_src[i & 1], d_dst[i & 1], d_sizes[i & 1], dst_stride)
                     pk.pack_batch(d_dst[i & 1], d_sizes[i & 1], packed[i & 1], totals[i & 1])
             torch.cuda.synchronize()
@@ -502,9 +510,14 @@ def main():
     # outside the timed region: both batches once more, their first and last streams against the oracle
     verified = None
     if decomp:  # the last decoded batch is the input again (lossless packers), and the decoder consumed every stream in full
-        last = (nstep[0] - 1) & 1
-        ok_len = bool(torch.equal(d_used, d_sizes[last]))
-        decode_ok = ok_len and (bool(torch.equal(d_back.view(-1), d_src[last].view(-1))) if args.packer in ("xdelta_hzr", "hzr") else True)
+        decode_ok = True
+        for h in range(S):
+            last = last_of_slot[h]
+            if last is None:
+                continue
+            decode_ok = decode_ok and bool(torch.equal(d_used[h], d_sizes[last]))
+            if args.packer in ("xdelta_hzr", "hzr"):
+                decode_ok = decode_ok and bool(torch.equal(d_back[h].view(-1), d_src[last].view(-1)))
     for s in range(2):
         pk.compress_batch(d_src[s], d_dst[s], d_sizes[s], dst_stride)
     torch.cuda.synchronize()
@@ -612,7 +625,8 @@ def main():
                              "inside the step, device-resident%s" % (args.packer, args.nb, total_blocks, shape,
                                                                 "; %d steps in flight per rank, each on its own handle and stream" % S if S > 1 else "")) if c5 else
                             ("%s nb=%d, %d blocks/GPU/step of %s (BASELINE configs[2] shape, xdelta_hzr path), two alternating batches, "
-                             "device-resident" % (args.packer, args.nb, B, shape)),
+                             "device-resident%s" % (args.packer, args.nb, B, shape,
+                                                    "; %d batches in flight, each on its own handle and stream" % S if S > 1 else "")),
                 "blocks_per_gpu": B,
                 "steps_in_flight": S,
                 "ms_per_step_one_in_flight": round(single_ms, 4) if single_ms is not None else None,
