@@ -44,7 +44,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"])
     ap.add_argument("--blocks", type=int, default=None, help="c3: blocks per GPU per step (default 64); c5: total blocks (default 1024)")
-    ap.add_argument("--slots", type=int, default=1, help="c5 only: steps in flight per rank, each on its own handle (its own plane workspace, the "
+    ap.add_argument("--slots", type=int, default=1, help="steps in flight per rank (c5; on one GPU also c3 and decompress lines), each on its own handle (its own plane workspace, the "
                     "reference's one packer object per worker) and stream, taken round-robin; small shards leave most of the GPU idle inside "
                     "every kernel of a step (DESIGN 6b)")
     ap.add_argument("--nch", type=int, default=None)
@@ -345,14 +345,15 @@ def main():
         first = rank * B
         total_blocks = world * B
     S = args.slots
-    if S < 1 or (S > 1 and not ((c5 and args.op == "compress") or (not c5 and args.op == "decompress"))):
-        sys.stderr.write("bench.py: --slots is for --workload c5 compress lines and for --op decompress\n")
+    decomp_op = args.op == "decompress"
+    if S < 1 or (S > 1 and not c5 and dist is not None):
+        sys.stderr.write("bench.py: --slots with --workload c3 is a one-GPU line (secondary packers, decompress)\n")
         sys.exit(2)
     pks = [api.SignalPacker(args.packer, args.bps, nch, ns, args.nb, device=local_rank) for _ in range(S)]
     pk = pks[0]
     for q in pks:
         q.reserve(B)
-    nbuf = 2 * S if c5 else 2  # every slot alternates between two buffer sets (as its handle alternates between two workspace sets)
+    nbuf = 2 if decomp_op else 2 * S  # every slot alternates between two buffer sets (as its handle alternates between two workspace sets)
     # synthetic input, resident in HBM: TWO distinct batches alternate in the timed loop (the front end's behaviour depends on
     # what the previous call left in the plane workspace); every rank gets different blocks (SURVEY 8d generator)
     d_src = [synth.synth_batch_native(B, nch, ns, first_block=first + s * total_blocks, bps=args.bps, device=dev) for s in range(nbuf)]
@@ -429,6 +430,11 @@ def main():
                 if lag is not None:
                     lag.step(packed[bs], totals[bs])
             return
+        if S > 1:  # one GPU, no exchange: batch n on handle and stream n % S, buffer set n % 2S
+            n = nstep[0] - 1
+            with torch.cuda.stream(slot_streams[n % S]):
+                pks[n % S].compress_batch(d_src[n % nbuf], d_dst[n % nbuf], d_sizes[n % nbuf], dst_stride)
+            return
         if slot_free[slot] is not None and not slot_free[slot].query():  # (two steps old: almost always done -- then no barrier packet)
             stream.wait_event(slot_free[slot])
         pk.compress_batch(d_src[slot], d_dst[slot], d_sizes[slot], dst_stride)
@@ -488,7 +494,8 @@ def main():
                         last_of_slot[0] = i & 1
                         continue
                     pk.compress_batch(d_src[i & 1], d_dst[i & 1], d_sizes[i & 1], dst_stride)
-                    pk.pack_batch(d_dst[i & 1], d_sizes[i & 1], packed[i & 1], totals[i & 1])
+                    if need_pack:
+                        pk.pack_batch(d_dst[i & 1], d_sizes[i & 1], packed[i & 1], totals[i & 1])
             torch.cuda.synchronize()
             single_ms = (time.perf_counter() - g0) / args.steps * 1e3
     # c3, N > 1: the streams of the last step travel to rank 0 once, outside the timed steps (sustained, rank 0's xGMI ingress
