@@ -482,3 +482,51 @@ def test_batch_calls_can_be_captured_into_a_graph(api, orc):
     torch.cuda.synchronize()
     assert [dst[1][b, : int(sz[1][b])].cpu().numpy().tobytes() for b in range(B)] == want[1]
     pk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nch,ns,B", [("xdelta_hzr", 12, 8192, 16), ("hadamard", 4, 65536, 3)])
+def test_several_handles_in_flight_give_the_sequential_streams(api, kind, nch, ns, B):
+    """Small batches in flight on several handles, each on its own stream and with no event between them (bench.py --slots,
+    INTEGRATION.md): every step's streams are the ones a single handle produces for that batch, and they decode back in flight
+    the same way."""
+    import torch
+
+    from rspt_amd import synth
+
+    S, steps = 3, 9
+    dev = torch.device("cuda", 0)
+    pks = [api.SignalPacker(kind, 4, nch, ns, 3) for _ in range(S)]
+    streams = [torch.cuda.ExternalStream(p.stream_ptr, device=dev) for p in pks]
+    stride = (pks[0].max_compressed_size + 255) // 256 * 256
+    srcs = [synth.synth_batch_native(B, nch, ns, first_block=n * B, device=dev) for n in range(steps)]
+    dst = [torch.zeros((B, stride), dtype=torch.uint8, device=dev) for _ in range(steps)]
+    sz = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(steps)]
+    back = [torch.zeros((B, pks[0].block_bytes), dtype=torch.uint8, device=dev) for _ in range(steps)]
+    used = [torch.zeros(B, dtype=torch.int64, device=dev) for _ in range(steps)]
+    for p in pks:
+        p.reserve(B)
+    for n in range(steps):
+        with torch.cuda.stream(streams[n % S]):
+            pks[n % S].compress_batch(srcs[n], dst[n], sz[n], stride)
+    for n in range(steps):  # (the decode of step n follows its encode on the same stream)
+        with torch.cuda.stream(streams[n % S]):
+            pks[n % S].decompress_batch(dst[n], B, stride, back[n], used[n])
+    torch.cuda.synchronize()
+    one = api.SignalPacker(kind, 4, nch, ns, 3)
+    for n in range(steps):
+        d1, s1 = one.compress_batch(srcs[n], None, None, stride)
+        torch.cuda.synchronize()
+        assert torch.equal(s1, sz[n]), n
+        for b in range(B):
+            m = int(s1[b])
+            assert torch.equal(d1[b, :m], dst[n][b, :m]), (n, b)
+        assert torch.equal(used[n], sz[n]), n
+        if kind == "xdelta_hzr":
+            assert torch.equal(back[n], srcs[n]), n
+        else:  # lossy: what the single handle decodes
+            b1, _ = one.decompress_batch(d1, B, stride)
+            torch.cuda.synchronize()
+            assert torch.equal(back[n], b1), n
+    for p in pks + [one]:
+        p.close()
