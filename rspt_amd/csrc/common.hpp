@@ -87,6 +87,15 @@ __device__ __forceinline__ uint32_t hb_index(const Geom& g, uint32_t b, uint32_t
 // ---------------------------------------------------------------------------
 // wave-level helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------
+// C's `(int)x` of a double AS THE REFERENCE'S BUILD COMPUTES IT: out of range is undefined in C, and the x86-64 conversion the
+// reference (and the oracle) compile to, cvttsd2si, returns 0x80000000 for everything it cannot represent -- too large, too small
+// or NaN.  The GPU's own conversion saturates (+overflow -> 0x7FFFFFFF, NaN -> 0): one count off in exactly those samples (found by
+// tools/soak.py on dct blocks whose coefficients overflow their two planes; signal_packer_dct.cpp:85,98, rspt_test.cpp:130).
+// (The test is on the high word: x >= 2^31, +inf or a NaN without sign bit <=> hi >= 0x41E00000 as a signed integer -- two full-rate
+// integer instructions beside the conversion, which matters in the IIR's recurrence wave.  Below -2^31 both conversions give
+// 0x80000000; a NaN with the sign bit set cannot arise from finite samples.)
+__device__ __forceinline__ int32_t trunc_i32_c(double x) { return __double2hiint(x) >= 0x41E00000 ? (int32_t)0x80000000u : (int32_t)x; }
+
 __device__ __forceinline__ uint32_t lane_id() { return __lane_id(); }
 
 // Cross-lane data movement goes through DPP (a VALU operand modifier, a few cycles) rather than

@@ -157,7 +157,7 @@ __device__ __forceinline__ void iir_channel(uint8_t* p, size_t stride, uint32_t 
 #pragma unroll
             for (int i = NC - 1; i > 0; --i) f.y[i] = f.y[i - 1];
             f.y[0] = a;
-            out[e] = (int32_t)a;  // C truncation (rspt_test.cpp:130)
+            out[e] = trunc_i32_c(a);  // C truncation (rspt_test.cpp:130)
         }
 #pragma unroll
         for (int i = 0; i < NC; ++i) f.x[i] = xs[CH + NC - 2 - i];  // the last NC inputs, newest first
@@ -175,7 +175,7 @@ __device__ __forceinline__ void iir_channel(uint8_t* p, size_t stride, uint32_t 
 #pragma unroll
         for (int i = 1; i < NC; ++i) a = (a - (c.n[i] * f.y[i]));
         f.y[0] = a;
-        iir_store<BPS>(q, (int32_t)a, aligned);
+        iir_store<BPS>(q, trunc_i32_c(a), aligned);
     }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_pipe(uint8_t* __restrict__ 
 #pragma unroll
                         for (int i = NC - 1; i > 0; --i) f.y[i] = f.y[i - 1];
                         f.y[0] = a;
-                        return (int32_t)a;  // C truncation (rspt_test.cpp:130)
+                        return trunc_i32_c(a);  // C truncation (rspt_test.cpp:130)
                     };
                     if (cnt == kIirChunk) {
                         // sixteen samples at a time: their feed-forward sums are read from LDS together (one wait), the results

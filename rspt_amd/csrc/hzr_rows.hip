@@ -24,6 +24,9 @@ namespace rspt {
 
 constexpr uint32_t kQueueEntries = 512;  // entries per wave in the sparse-row queue (8 x 64)
 static_assert(kTokQueueBase + kEncWaves * kQueueEntries <= kStageWords, "emit-phase queues sit in the image tail");
+// k_encode's own token count of a block (own_bits): sixteen per-wave histograms at the start of the image, the queues behind them
+constexpr uint32_t kOwnHistQueueBase = kEncWaves * kSymStride;
+static_assert(kOwnHistQueueBase >= kTokQueueBase && kOwnHistQueueBase + kEncWaves * kQueueEntries <= kStageWords, "own-count queues: behind the histograms, inside the image");
 
 // trailing (highest-address) zero bytes of a granule that is not all zero
 __device__ __forceinline__ uint32_t trail_zero_bytes(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3) {
@@ -869,7 +872,11 @@ __device__ __forceinline__ void encode_block_rows(uint32_t hb, uint8_t* __restri
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             ListSink none{nullptr, kListNone};
-            hist_rows(W, rc, in_size, myhist, d.runcls, d.stage + kTokQueueBase + w * kQueueEntries, none);
+            // (the sparse-row queues of this pass start BEHIND the sixteen histograms: from kTokQueueBase = 4200 on, where the emit
+            //  phase keeps them, wave 0's first 24 queue entries were wave 15's bins 240..263 -- the block-end run that wave 15 counts
+            //  landed in entries wave 0 was reading back, and its own first entries in those bins: a wrong segment offset now and then,
+            //  i.e. a damaged payload in about every second launch of such a block; tools/soak.py seed 1731)
+            hist_rows(W, rc, in_size, myhist, d.runcls, d.stage + kOwnHistQueueBase + w * kQueueEntries, none);
             __builtin_amdgcn_wave_barrier();
             uint32_t bits = 0;
             for (uint32_t s = l; s < (uint32_t)kNumSym; s += 64) bits += myhist[s] * (d.tab[s].y + run_extra_bits(s));  // (unused symbols: count 0)

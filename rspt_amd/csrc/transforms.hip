@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_dct(const int32_t* __restrict__ in, Geo
                 s = __dmul_rn(sum[cc], i == 0 ? scale0 : scale1);  // sum *= Cs[i]*sqrt(2/n)/128 (dct.cpp:84)
             else
                 s = __dmul_rn(sum[cc], scale1);                    // sum *= sqrt(2/n)*128 (dct.cpp:97)
-            int32_t r = (int32_t)s;                                  // C truncation (dct.cpp:85,98)
+            int32_t r = trunc_i32_c(s);                              // C truncation (dct.cpp:85,98)
             if (!FORWARD) r = (int32_t)((uint32_t)r + (uint32_t)s_mean[cc]);
             out[(size_t)b * g.N + (size_t)(c0 + cc) * n + i] = r;
         }
@@ -686,11 +686,11 @@ __global__ __launch_bounds__(1024) void k_dctfft_rows(const double2* __restrict_
             const double2 pw = post[k];
             const double cval = pw.x * z.x + pw.y * z.y;            // Re(e^{-i pi k/2n} V[k])
             const double sres = cval * (k == 0 ? scale0 : scale1);  // Cs[k]*sqrt(2/n)/128 (dct.cpp:84)
-            orow[k] = (int32_t)sres;                                  // C truncation (dct.cpp:85)
+            orow[k] = trunc_i32_c(sres);                              // C truncation (dct.cpp:85)
         } else {
             const uint32_t i = k < (n >> 1) ? 2u * k : 2u * (n - 1u - k) + 1u;
             const double sres = z.x * scale1;  // sqrt(2/n)*128 (dct.cpp:97)
-            orow[i] = (int32_t)((uint32_t)(int32_t)sres + (uint32_t)mean);
+            orow[i] = (int32_t)((uint32_t)trunc_i32_c(sres) + (uint32_t)mean);
         }
     }
 }
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(1024) void k_dctr_rows(const double2* __restrict__ 
     // C[x] = trunc(Re(e^{-i pi x / 2n} V) * Cs[x]*sqrt(2/n)/128)   (dct.cpp:84-85)
     auto emit = [&](uint32_t x, double vr, double vi) {
         const double2 pw = post[x];
-        orow[x] = (int32_t)((pw.x * vr + pw.y * vi) * (x == 0 ? scale0 : scale1));
+        orow[x] = trunc_i32_c((pw.x * vr + pw.y * vi) * (x == 0 ? scale0 : scale1));
     };
     auto pair_out = [&](uint32_t k, const double2& za, const double2& zb) {  // za = Z[k], zb = Z[M-k]; 0 < k < M, k != M/2
         const double er = 0.5 * (za.x + zb.x), ei = 0.5 * (za.y - zb.y);     // E
@@ -885,7 +885,7 @@ __global__ __launch_bounds__(1024) void k_idctr_rows(const double2* __restrict__
     const int32_t mean = load_mean_hdr(means, g, b, c);
     auto put = [&](uint32_t j, double v) {  // v[j] -> its sample: s[2j] = v[j] (j < n/2), s[2j+1] = v[n-1-j]
         const uint32_t i = j < (n >> 1) ? 2u * j : 2u * (n - 1u - j) + 1u;
-        orow[i] = (int32_t)((uint32_t)(int32_t)(v * scale1) + (uint32_t)mean);  // sqrt(2/n)*128, C truncation (dct.cpp:97-98)
+        orow[i] = (int32_t)((uint32_t)trunc_i32_c(v * scale1) + (uint32_t)mean);  // sqrt(2/n)*128, C truncation (dct.cpp:97-98)
     };
     for (uint32_t idx = threadIdx.x; idx < total; idx += blockDim.x) {
         const uint32_t r = idx & (R - 1), k2 = idx >> lr;

@@ -134,3 +134,38 @@ def test_random_batch_matches_single_calls(api, orc):
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.from_numpy(np.stack(blocks))) and torch.equal(used, d_sizes)
     pk.close()
+
+
+def test_blocks_with_one_populated_segment_every_launch(api, orc):
+    """hzr blocks with a single non-zero 4 KiB segment that holds more tokens than the one-wave encoder takes: k_tree takes their
+    histogram itself and k_encode counts each wave's tokens once more for the segment offsets (own_bits).  In that pass the
+    sparse-row queue of wave 0 used to overlap the last bins of wave 15's histogram in LDS -- wave 15 counts the run that reaches
+    the block end right there -- and about every second launch produced a damaged payload (found by tools/soak.py, round 4).
+    A race: so the same batch many times over."""
+    import torch
+
+    r = np.random.default_rng(77)
+    blocks = []
+    for seg in (0, 0, 3, 15, 0, 7):
+        x = np.zeros(65536 * 2 + 4096, dtype=np.uint8)
+        for blk in range(3):
+            n = 4096 if blk < 2 else 2048
+            lo = blk * 65536 + (seg * 4096 if blk < 2 else 0)
+            pos = lo + np.sort(r.choice(n, size=n // 6, replace=False))
+            x[pos] = r.integers(1, 256, pos.size)
+        blocks.append(x)
+    n = blocks[0].size
+    pk = api.new_hzr(1, 1, n)
+    po = orc.packer("hzr", 1, 1, n)
+    want = [po.compress(b) for b in blocks]
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    stride = (pk.max_compressed_size + 255) // 256 * 256
+    for rep in range(40):
+        d_dst = torch.zeros((len(blocks), stride), dtype=torch.uint8, device="cuda")
+        d_sizes = torch.zeros(len(blocks), dtype=torch.int64, device="cuda")
+        pk.compress_batch(d_src, d_dst, d_sizes, stride)
+        torch.cuda.synchronize()
+        for i, w in enumerate(want):
+            got = d_dst[i, : int(d_sizes[i])].cpu().numpy().tobytes()
+            assert got == w, "launch %d block %d: %s" % (rep, i, describe_mismatch(got, w))
+    pk.close()

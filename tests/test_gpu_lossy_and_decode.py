@@ -354,3 +354,23 @@ def test_hadamard_beyond_65536_points(api, orc, golden, name):
     dec = dec[0] if isinstance(dec, tuple) else dec
     assert zlib.crc32(bytes(dec)) == g["decoded_crc32"]
     pk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bps,nch,ns,amp", [(4, 8, 2048, 1 << 29), (3, 4, 2048, 1 << 21), (4, 1, 3000, 1 << 29), (4, 3, 257, (1 << 31) - 1)])
+def test_dct_decode_where_the_truncation_overflows(api, orc, bps, nch, ns, amp):
+    """dct blocks far outside the packer's range (coefficients overflow their two planes): the decoded doubles pass 2^31, where C's
+    `(int)x` is undefined and the reference's build (x86-64 cvttsd2si) returns 0x80000000 for every unrepresentable value -- the
+    GPU's own conversion saturates, one count off for the positive ones (signal_packer_dct.cpp:98; found by tools/soak.py).
+    Streams and decoded blocks equal the oracle's."""
+    for seed in range(3):
+        x = cases._rand_native(nch, ns, bps, 9100 + seed, amp, walk=bool(seed & 1))
+        po = orc.packer("dct", bps, nch, ns)
+        pk = api.SignalPacker("dct", bps, nch, ns)
+        want = po.compress(x)
+        got = pk.compress(x)
+        assert got == want
+        ref, used_ref, _ = po.decompress(want)
+        dec, used = pk.decompress(got)
+        assert used == len(got) and dec == ref
+        pk.close()

@@ -142,3 +142,22 @@ def test_gpu_prefilter_full_size_block(api, golden, mode, init):
     for b in range(2):
         assert zlib.crc32(d_buf[b].cpu().numpy().tobytes()) == want["crc32"], "block %d" % b
     pk.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["shared", "per_channel"])
+def test_gpu_prefilter_at_full_scale(api, orc, mode):
+    """int32 samples near full scale: the band-pass overshoots past 2^31 in places, where `(int)double` is what the reference's
+    x86-64 build makes of it (0x80000000), not the GPU's saturating conversion (rspt_test.cpp:130; found by tools/soak.py)"""
+    import torch
+
+    nch, ns, bps = 5, 5000, 4
+    data = cases._rand_native(nch, ns, bps, 424242, (1 << 31) - 1, walk=False)
+    pk = api.new_xdelta_hzr(bps, nch, ns, 3)
+    for coef in (cases.IIR_BANDPASS, cases.IIR_HIGHPASS):
+        d_buf = torch.from_numpy(np.stack([data, data])).cuda()
+        pk.iir_prefilter_batch(d_buf, coef[0], coef[1], 2000, per_channel=mode == "per_channel")
+        torch.cuda.synchronize()
+        want = orc.iir_prefilter(data, bps, nch, ns, coef[0], coef[1], 2000, shared_state=mode == "shared")
+        assert d_buf[0].cpu().numpy().tobytes() == want and d_buf[1].cpu().numpy().tobytes() == want
+    pk.close()

@@ -116,3 +116,29 @@ def test_hadamard_beyond_65536_points_golden(orc, golden, name):
     dec, used, rc = pk.decompress(s)
     assert rc == 0 and used == len(s) and zlib.crc32(dec) == g["decoded_crc32"]
     pk.close()
+
+
+@pytest.mark.parametrize("bps,nch,ns,amp", [(4, 8, 2048, 1 << 29), (3, 4, 2048, 1 << 21), (4, 1, 3000, 1 << 29), (4, 3, 257, (1 << 31) - 1)])
+def test_dct_beyond_its_range_restatement_equals_the_reference(orc, ref, bps, nch, ns, amp):
+    """Out of the dct packer's range the decoded doubles overflow int32 and `(int)x` (signal_packer_dct.cpp:98) is whatever the
+    build makes of it: the reference compiled here (oracle/_ref, x86-64: 0x80000000) is the authority, the restatement follows
+    it -- and the GPU path follows the restatement (tests/test_gpu_lossy_and_decode.py, same shapes)."""
+    for seed in range(3):
+        x = cases._rand_native(nch, ns, bps, 9100 + seed, amp, walk=bool(seed & 1))
+        po, pr = orc.packer("dct", bps, nch, ns), ref.packer("dct", bps, nch, ns)
+        s = po.compress(x)
+        assert s == pr.compress(x)
+        assert po.decompress(s)[0] == pr.decompress(s)[0]
+
+
+def test_iir_at_full_scale_restatement_equals_the_reference(orc, ref):
+    """the band-pass overshoots past 2^31 on full-scale int32 input: the truncated double is the reference build's (rspt_test.cpp:130)"""
+    nch, ns, bps = 5, 5000, 4
+    data = cases._rand_native(nch, ns, bps, 424242, (1 << 31) - 1, walk=False)
+    for coef in (cases.IIR_BANDPASS, cases.IIR_HIGHPASS):
+        a = orc.iir_prefilter(data, bps, nch, ns, coef[0], coef[1], 2000)
+        assert a == ref.iir_prefilter(data, bps, nch, ns, coef[0], coef[1], 2000)
+        v = orc.native_to_i32(np.frombuffer(a, dtype=np.uint8), ns, nch, bps)
+        x = orc.native_to_i32(data, ns, nch, bps)
+    # (the case is only worth its name if the overflow happens)
+    assert (v == -(1 << 31)).any() or (np.abs(v.astype(np.int64)) > np.abs(x.astype(np.int64)).max()).any()

@@ -1,0 +1,247 @@
+"""Time-bounded randomised parity soak on the GPU: random packers, sample widths, geometries, amplitudes, byte orders and batch
+sizes -- every produced stream against the CPU oracle (oracle/: the restatement pinned by the reference build), every decode against
+the input (lossless packers) or the oracle's decode (lossy ones).  Not a test (it runs as long as it is told to); a mismatch prints
+the seed of the case, which reproduces it.
+
+    python tools/soak.py [seconds, default 300] [first seed, default 1]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import cases
+from streamtools import describe_mismatch, parse_stream
+from test_gpu_fuzz import KINDS as BYTE_KINDS, _gen as gen_bytes
+from oracle.oracle import Oracle
+from rspt_amd import api
+
+orc = Oracle()
+
+
+def pick_shape(r, kind):
+    if kind == "hadamard":
+        ns = 1 << int(r.integers(4, 18))  # 16 .. 131072 (two-pass transform above 65536)
+        nch = int(r.integers(1, max(2, min(40, (1 << 21) // ns))))
+        return nch, ns
+    if kind == "dct":
+        ns = int(r.choice([16, 100, 257, 1000, 1024, 2048, 3000]))
+        return int(r.integers(1, 9)), ns
+    style = int(r.integers(0, 5))
+    if style == 0:  # many channels, short
+        return int(r.integers(33, 200)), int(r.integers(1, 600))
+    if style == 1:  # few channels, long, ragged
+        return int(r.integers(1, 6)), int(r.integers(3000, 300000))
+    if style == 2:  # the shapes of the BASELINE configs, cut down
+        return int(r.choice([12, 64])), int(r.choice([8192, 4096, 16384, 65536 // 4]))
+    if style == 3:  # tiny
+        return int(r.integers(1, 5)), int(r.integers(1, 40))
+    return int(r.integers(1, 70)), int(r.integers(16, 9000))
+
+
+def iir_case(seed, r):
+    """the pre-filter stage (rspt_test.cpp:116-136): both modes against the restatement, amplitudes up to full scale (the truncated
+    double overflows int32 there: the reference's conversion, not the GPU's saturating one, decides what comes out)"""
+    bps = int(r.choice([4, 4, 3, 2]))
+    nch, ns = int(r.integers(1, 20)), int(r.choice([1, 5, 100, 2000, 2047, 2048, 2049, 5000, 40000]))
+    n, d = (cases.IIR_BANDPASS, cases.IIR_BANDPASS, cases.IIR_LOWPASS, cases.IIR_HIGHPASS)[int(r.integers(0, 4))]
+    init = int(r.choice([0, 3, 2000]))
+    lim = 1 << (8 * bps - 1)
+    amp = int(min(lim - 1, r.choice([100, 1 << 14, 1 << 21, 1 << 29, (1 << 31) - 1])))
+    desc = "seed %d: iir int%d %dch x %d init %d amp %d" % (seed, 8 * bps, nch, ns, init, amp)
+    data = cases._rand_native(nch, ns, bps, int(r.integers(1 << 30)), amp, walk=bool(r.integers(2)))
+    pk = api.new_xdelta_hzr(bps, nch, ns, 3)
+    bad = []
+    for shared in (True, False):
+        d_buf = torch.from_numpy(np.stack([data, data])).cuda()
+        pk.iir_prefilter_batch(d_buf, n, d, init, per_channel=not shared)
+        torch.cuda.synchronize()
+        want = orc.iir_prefilter(data, bps, nch, ns, n, d, init, shared_state=shared)
+        for b in range(2):
+            got = d_buf[b].cpu().numpy().tobytes()
+            if got != want:
+                a_ = np.frombuffer(got, dtype=np.uint8).reshape(-1, bps)
+                b_ = np.frombuffer(want, dtype=np.uint8).reshape(-1, bps)
+                diff = np.nonzero((a_ != b_).any(axis=1))[0]
+                bad.append("%s mode, block %d: %d of %d samples differ, first at %s" % ("shared" if shared else "per-channel", b, diff.size, a_.shape[0], diff[:4].tolist()))
+    pk.close()
+    return (2, bad), desc
+
+
+def bytes_case(seed, r):
+    """byte streams of every density through a 1-channel 8-bit hzr packer (plane 0 of its stream IS hzr_encode(data)): pieces of
+    different kinds spliced together, zero stretches between them -- blocks with one populated segment, runs across block
+    edges, Fill / PlainCopy / light / small blocks side by side; a batch of them, twice on the same handle"""
+    pieces, total = [], int(r.integers(1, 400000))
+    while sum(p.size for p in pieces) < total:
+        k = str(r.choice(BYTE_KINDS + ["zeros", "zeros"]))
+        ln = int(r.choice([1, 17, 300, 4096, 5000, 40000, 65536, 70000, 150000]))
+        if ln < 1000 and k not in ("zeros", "dense", "noise", "const", "peaky"):
+            k = "dense"  # (the other generators want room)
+        pieces.append(np.zeros(ln, dtype=np.uint8) if k == "zeros" else gen_bytes(int(r.integers(1 << 30)), ln, k))
+    base = np.concatenate(pieces)[:total]
+    n = base.size
+    desc = "seed %d: bytes n %d" % (seed, n)
+    B = int(r.integers(1, 5))
+    blocks = [base] + [np.roll(base, int(r.integers(1, n + 1))) for _ in range(B - 1)]
+    pk = api.new_hzr(1, 1, n)
+    po = orc.packer("hzr", 1, 1, n)
+    want = [po.compress(b) for b in blocks]
+    bad = []
+    d_src = torch.from_numpy(np.stack(blocks)).cuda()
+    for call in range(2):
+        d_dst, d_sizes = pk.compress_batch(d_src)
+        torch.cuda.synchronize()
+        sizes = d_sizes.cpu().numpy()
+        out = d_dst.cpu().numpy()
+        d_out, d_used = pk.decompress_batch(d_dst, B, d_dst.shape[1])
+        torch.cuda.synchronize()
+        for i in range(B):
+            got = out[i, : sizes[i]].tobytes()
+            if got != want[i]:
+                bad.append("call %d block %d of %d: stream differs: %s" % (call, i, B, describe_mismatch(got, want[i])[:600]))
+            elif int(d_used[i]) != sizes[i] or d_out[i].cpu().numpy().tobytes() != blocks[i].tobytes():
+                bad.append("call %d block %d of %d: decode differs (consumed %d of %d)" % (call, i, B, int(d_used[i]), sizes[i]))
+    pk.close()
+    po.close()
+    return (2 * B, bad), desc
+
+
+def one_case(seed, keep=None):
+    r = np.random.default_rng(seed)
+    kind = str(r.choice(["xdelta_hzr", "xdelta_hzr", "xdelta_hzr", "hzr", "hadamard", "dct", "iir"]))
+    rb = np.random.default_rng(seed ^ 0x5EED0000)  # (a generator of its own: the seeds of the other kinds mean what they meant before this kind existed)
+    if keep is None and rb.integers(0, 4) == 0:
+        return bytes_case(seed, rb)
+    if kind == "iir":
+        return iir_case(seed, r)
+    bps = int(r.choice([4, 4, 3, 2, 1]))
+    nch, ns = pick_shape(r, kind)
+    nb0 = int(r.integers(1, 5)) if kind in ("xdelta_hzr", "hzr") else 3
+    if kind == "hzr":
+        nb0 = int(r.integers(1, bps + 1)) if bps < 4 else nb0
+    be = bool(r.integers(0, 4) == 0) and bps > 1
+    calls = int(r.integers(1, 4))
+    desc = "seed %d: %s int%d %dch x %d nb %d%s" % (seed, kind, 8 * bps, nch, ns, nb0, " big-endian" if be else "")
+    try:
+        po = orc.packer(kind, bps, nch, ns, nb0)
+    except ValueError:
+        return None, desc + " (refused by the oracle)"
+    try:
+        pk = api.SignalPacker(kind, bps, nch, ns, nb0)
+    except api.RsptHipError as e:
+        po.close()
+        return None, desc + " (refused by the library: %s)" % e
+    if be:
+        pk.set_byte_order(big_endian=True)
+    bad = []
+    nblocks = 0
+    lim = 1 << (8 * bps - 1)
+    for call in range(calls):
+        B = int(r.integers(1, 5)) if nch * ns < (1 << 20) else 1
+        amps = [int(min(lim - 1, r.choice([1, 3, 60, 1 << 7, 1 << 10, 1 << 14, 1 << 21, 1 << 29]))) for _ in range(B)]
+        blocks = [cases._rand_native(nch, ns, bps, int(r.integers(1 << 30)), max(1, a), walk=bool(r.integers(2))) for a in amps]
+        if r.integers(0, 6) == 0:
+            blocks[0] = np.zeros_like(blocks[0])  # an all-zero block now and then
+        feed = [np.ascontiguousarray(b.reshape(-1, bps)[:, ::-1]).reshape(-1) if be else b for b in blocks]
+        want, ref = [], []
+        for b in blocks:  # (the oracle's object decodes with the nb it has reached, too: each stream right behind its compress call)
+            want.append(po.compress(b))
+            ref.append(po.decompress(want[-1])[0])
+        if keep is not None:
+            keep.append(dict(kind=kind, bps=bps, nch=nch, ns=ns, nb0=nb0, be=be, feed=feed, want=want))
+        if r.integers(0, 2) == 0 or B == 1:  # the host-pointer entry point, block by block
+            got, dec = [], []
+            for f in feed:  # (decoded at once: a stream carries no nb, the handle decodes with the nb it has reached -- like the reference's object)
+                got.append(pk.compress(f))
+                dec.append(pk.decompress(got[-1])[0])
+        else:  # one device-resident batch
+            d_src = torch.from_numpy(np.stack(feed)).cuda()
+            d_dst, d_sizes = pk.compress_batch(d_src)
+            torch.cuda.synchronize()
+            sizes = d_sizes.cpu().numpy()
+            out = d_dst.cpu().numpy()
+            got = [out[i, : sizes[i]].tobytes() for i in range(B)]
+            stride = d_dst.shape[1]
+            d_out, d_used = pk.decompress_batch(d_dst, B, stride)
+            torch.cuda.synchronize()
+            dec = [d_out[i].cpu().numpy().tobytes() for i in range(B)]
+            used = d_used.cpu().numpy()
+            for i in range(B):
+                # the batch is decoded with the nb the handle ended on: streams written before an escalation inside this batch have
+                # fewer planes and cannot be decoded by this handle any more (nor by the reference's object)
+                if kind == "xdelta_hzr" and len(parse_stream(got[i])["planes"]) != pk.nb:
+                    dec[i] = None
+                elif used[i] != sizes[i]:
+                    bad.append("call %d block %d: decode consumed %d of %d" % (call, i, used[i], sizes[i]))
+        for i in range(B):
+            nblocks += 1
+            if got[i] != want[i]:
+                hl = 3 * nch if kind in ("dct", "hadamard") else 0
+                bad.append("call %d block %d of %d (amp %d, %s): stream differs (%d vs %d bytes): %s"
+                           % (call, i, B, amps[i], "batch" if len(blocks) > 1 and dec[i] is not None and B > 1 else "-", len(got[i]), len(want[i]), describe_mismatch(got[i], want[i], hl)))
+                continue
+            if dec[i] is None:
+                continue
+            ref_dec = ref[i]
+            ref_feed = np.ascontiguousarray(np.frombuffer(ref_dec, dtype=np.uint8).reshape(-1, bps)[:, ::-1]).reshape(-1).tobytes() if be else ref_dec
+            if dec[i] != ref_feed:
+                a_ = np.frombuffer(dec[i], dtype=np.uint8).reshape(-1, bps)
+                b_ = np.frombuffer(ref_feed, dtype=np.uint8).reshape(-1, bps)
+                diff = np.nonzero((a_ != b_).any(axis=1))[0]
+
+                def val(rows):
+                    le = rows[:, ::-1] if be else rows
+                    v = np.zeros(rows.shape[0], dtype=np.int64)
+                    for q in range(bps):
+                        v |= le[:, q].astype(np.int64) << (8 * q)
+                    return (v ^ (1 << (8 * bps - 1))) - (1 << (8 * bps - 1))
+
+                src_ = val(feed[i].reshape(-1, bps)[diff[:4]])
+                bad.append("call %d block %d (amp %d): decode differs from the oracle's in %d of %d samples; first at %s: ours %s, oracle %s, input %s"
+                           % (call, i, amps[i], diff.size, a_.shape[0], diff[:4].tolist(), val(a_[diff[:4]]).tolist(), val(b_[diff[:4]]).tolist(), src_.tolist()))
+            if kind == "xdelta_hzr" and dec[i] != feed[i].tobytes():
+                bad.append("call %d block %d: lossless round trip differs" % (call, i))
+        if kind == "xdelta_hzr" and pk.nb != orc.packer_nb(po):
+            bad.append("call %d: nb %d, oracle %d" % (call, pk.nb, orc.packer_nb(po)))
+    pk.close()
+    po.close()
+    return (nblocks, bad), desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0 = time.time()
+    seed = seed0
+    ncases = nblocks = nbad = nrefused = 0
+    last = t0
+    while time.time() - t0 < budget:
+        res, desc = one_case(seed)
+        if res is None:
+            nrefused += 1
+        else:
+            ncases += 1
+            nblocks += res[0]
+            if res[1]:
+                nbad += 1
+                print("MISMATCH " + desc)
+                for b in res[1][:6]:
+                    print("    " + b)
+                sys.stdout.flush()
+        if time.time() - last > 45:
+            print("... %d cases (%d blocks), %d refused, %d bad, seed %d, %.0f s" % (ncases, nblocks, nrefused, nbad, seed, time.time() - t0), flush=True)
+            last = time.time()
+        seed += 1
+    print("soak: seeds %d..%d, %d cases, %d blocks compared with the oracle, %d shapes refused, %d cases with a mismatch, %.0f s"
+          % (seed0, seed - 1, ncases, nblocks, nrefused, nbad, time.time() - t0))
+    sys.exit(1 if nbad else 0)
+
+
+if __name__ == "__main__":
+    main()
