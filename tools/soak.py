@@ -33,6 +33,8 @@ def pick_shape(r, kind):
         ns = int(r.choice([16, 100, 257, 1000, 1024, 2048, 3000]))
         return int(r.integers(1, 9)), ns
     style = int(r.integers(0, 5))
+    if r.integers(0, 40) == 0:  # now and then the BASELINE shapes at full size
+        return (64, 65536) if r.integers(0, 2) else (12, 34199)
     if style == 0:  # many channels, short
         return int(r.integers(33, 200)), int(r.integers(1, 600))
     if style == 1:  # few channels, long, ragged
@@ -172,6 +174,37 @@ def one_case(seed, keep=None):
             torch.cuda.synchronize()
             dec = [d_out[i].cpu().numpy().tobytes() for i in range(B)]
             used = d_used.cpu().numpy()
+            # the batch as one container and back: the index carries every stream's own nb, so ALL streams decode (on a fresh handle)
+            d_packed, d_total = pk.pack_batch(d_dst, d_sizes)
+            torch.cuda.synchronize()
+            pk2 = api.SignalPacker(kind, bps, nch, ns, nb0)
+            if be:
+                pk2.set_byte_order(big_endian=True)
+            try:
+                p_out, p_used = pk2.decompress_packed(d_packed, nbytes=int(d_total))
+                torch.cuda.synchronize()
+                for i in range(B):
+                    if int(p_used[i]) != sizes[i]:
+                        bad.append("call %d block %d: container decode consumed %d of %d" % (call, i, int(p_used[i]), sizes[i]))
+                    elif kind == "xdelta_hzr" and p_out[i].cpu().numpy().tobytes() != feed[i].tobytes():
+                        bad.append("call %d block %d: container round trip differs" % (call, i))
+            except api.RsptHipError as e:
+                bad.append("call %d: container decode failed: %s" % (call, e))
+            # ... and the same blocks through the host pipeline (upload | compress | download) on that fresh handle: a loop of compress calls
+            if kind in ("xdelta_hzr", "hzr") and r.integers(0, 2) == 0:
+                pk3 = api.SignalPacker(kind, bps, nch, ns, nb0)
+                po3 = orc.packer(kind, bps, nch, ns, nb0)
+                if be:
+                    pk3.set_byte_order(big_endian=True)
+                hs = np.concatenate(feed)
+                ho = np.zeros((B, (pk3.max_compressed_size + 63) // 64 * 64), dtype=np.uint8)
+                lens = pk3.compress_many(hs, ho)
+                for i in range(B):
+                    if ho[i, : lens[i]].tobytes() != po3.compress(blocks[i]):
+                        bad.append("call %d block %d: compress_many stream differs" % (call, i))
+                pk3.close()
+                po3.close()
+            pk2.close()
             for i in range(B):
                 # the batch is decoded with the nb the handle ended on: streams written before an escalation inside this batch have
                 # fewer planes and cannot be decoded by this handle any more (nor by the reference's object)
