@@ -35,6 +35,8 @@ def pick_shape(r, kind):
     style = int(r.integers(0, 5))
     if r.integers(0, 40) == 0:  # now and then the BASELINE shapes at full size
         return (64, 65536) if r.integers(0, 2) else (12, 34199)
+    if r.integers(0, 30) == 0:  # very wide / very long
+        return (int(r.integers(300, 1500)), int(r.integers(1, 200))) if r.integers(0, 2) else (int(r.integers(1, 3)), int(r.integers(300000, 2200000)))
     if style == 0:  # many channels, short
         return int(r.integers(33, 200)), int(r.integers(1, 600))
     if style == 1:  # few channels, long, ragged
@@ -114,12 +116,75 @@ def bytes_case(seed, r):
     return (2 * B, bad), desc
 
 
+def feed_case(seed, r):
+    """rspt_hip_feed_*: blocks pushed as they arrive, polled at random moments, a submit now and then == a loop of compress calls;
+    then decompress_many of what came out (with the nb the sequence ended on: only streams written with it)"""
+    kind = str(r.choice(["xdelta_hzr", "xdelta_hzr", "hzr"]))
+    bps = int(r.choice([4, 3, 2, 1]))
+    nch, ns = int(r.integers(1, 40)), int(r.integers(1, 6000))
+    nb0 = int(r.integers(1, 5))
+    n = int(r.integers(1, 40))
+    group, slots = int(r.integers(1, 9)), int(r.integers(2, 5))
+    desc = "seed %d: feed %s int%d %dch x %d nb %d, %d blocks, groups of %d, %d slots" % (seed, kind, 8 * bps, nch, ns, nb0, n, group, slots)
+    lim = 1 << (8 * bps - 1)
+    step = int(r.integers(0, n + 1))
+    blocks = [cases._rand_native(nch, ns, bps, int(r.integers(1 << 30)), max(1, min(lim - 1, 2000 if i < step else 1 << 27)), walk=bool(i & 1)) for i in range(n)]
+    po = orc.packer(kind, bps, nch, ns, nb0)
+    want = [po.compress(b) for b in blocks]
+    pk = api.SignalPacker(kind, bps, nch, ns, nb0)
+    cap = pk.max_compressed_size
+    dst = [np.zeros(cap, dtype=np.uint8) for _ in range(n)]
+    got, bad = {}, []
+
+    def drain():
+        while True:
+            q = pk.feed_poll()
+            if q is None:
+                return
+            got[q[0]] = q[1:]
+
+    pk.feed_begin(group, slots)
+    for i in range(n):
+        while not pk.feed_push(blocks[i], dst[i]):
+            drain()
+        if r.integers(0, 4) == 0:
+            drain()
+        if r.integers(0, 9) == 0:
+            pk.feed_submit()
+    pk.feed_flush()
+    drain()
+    pk.feed_end()
+    if sorted(got) != list(range(n)):
+        bad.append("polled %s of %d blocks" % (sorted(got), n))
+    for i in range(n):
+        if i in got and (got[i][1] != 0 or dst[i][: got[i][0]].tobytes() != want[i]):
+            bad.append("block %d: status %d, length %d (want %d)%s" % (i, got[i][1], got[i][0], len(want[i]), "" if got[i][1] else ": stream differs"))
+    if not bad and kind == "xdelta_hzr":
+        nbf = pk.nb
+        keep_i = [i for i in range(n) if len(parse_stream(want[i])["planes"]) == nbf]
+        if keep_i:
+            stride = (cap + 63) // 64 * 64
+            st = np.zeros((len(keep_i), stride), dtype=np.uint8)
+            for q, i in enumerate(keep_i):
+                st[q, : len(want[i])] = np.frombuffer(want[i], dtype=np.uint8)
+            back = np.zeros(len(keep_i) * pk.block_bytes, dtype=np.uint8)
+            used = pk.decompress_many(st, back)
+            for q, i in enumerate(keep_i):
+                if used[q] != len(want[i]) or back[q * pk.block_bytes : (q + 1) * pk.block_bytes].tobytes() != blocks[i].tobytes():
+                    bad.append("decompress_many: block %d differs (consumed %d of %d)" % (i, used[q], len(want[i])))
+    pk.close()
+    po.close()
+    return (n, bad), desc
+
+
 def one_case(seed, keep=None):
     r = np.random.default_rng(seed)
     kind = str(r.choice(["xdelta_hzr", "xdelta_hzr", "xdelta_hzr", "hzr", "hadamard", "dct", "iir"]))
     rb = np.random.default_rng(seed ^ 0x5EED0000)  # (a generator of its own: the seeds of the other kinds mean what they meant before this kind existed)
     if keep is None and rb.integers(0, 4) == 0:
         return bytes_case(seed, rb)
+    if keep is None and rb.integers(0, 12) == 0:
+        return feed_case(seed, rb)
     if kind == "iir":
         return iir_case(seed, r)
     bps = int(r.choice([4, 4, 3, 2, 1]))
@@ -258,6 +323,8 @@ def main():
         res, desc = one_case(seed)
         if res is None:
             nrefused += 1
+            if nrefused <= 8:
+                print("refused: " + desc, flush=True)
         else:
             ncases += 1
             nblocks += res[0]
