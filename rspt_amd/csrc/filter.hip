@@ -294,20 +294,28 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_pipe(uint8_t* __restrict__ 
                 } else if (t <= nchunks) {
                     const uint32_t k = t - 1, bi = k & 1u;
                     const uint32_t cnt = min(kIirChunk, ns - k * kIirChunk);
-                    auto one = [&](double a) -> int32_t {
+                    auto rec = [&](double a) -> double {
 #if defined(IIR_PROBE) && IIR_PROBE == 1  // timing probe (never in the product): no recurrence
-                        return (int32_t)a;
+                        return a;
 #endif
 #pragma unroll
                         for (int i = 1; i < NC; ++i) a = a - c.n[i] * f.y[i - 1];  // (y[i-1] now = y[i] of the step being taken)
 #pragma unroll
                         for (int i = NC - 1; i > 0; --i) f.y[i] = f.y[i - 1];
                         f.y[0] = a;
-                        return trunc_i32_c(a);  // C truncation (rspt_test.cpp:130)
+                        return a;
                     };
                     if (cnt == kIirChunk) {
                         // sixteen samples at a time: their feed-forward sums are read from LDS together (one wait), the results
-                        // written together -- per sample the wave issues the recurrence and little else
+                        // written together -- per sample the wave issues the recurrence and little else.  The truncation is the
+                        // GPU's own (saturating) conversion here; C's as the reference's build does it (trunc_i32_c, common.hpp) differs
+                        // from it only where the double is out of range, i.e. where this conversion returns INT_MAX: the largest
+                        // result of the chunk is tracked (half an instruction per sample instead of two), and a chunk that
+                        // reaches INT_MAX -- full-scale input through a filter that overshoots -- is done once more, exactly.
+                        double ysave[NC];
+#pragma unroll
+                        for (int i = 0; i < NC; ++i) ysave[i] = f.y[i];
+                        int32_t mx = (int32_t)0x80000000u;
 #pragma unroll 1
                         for (uint32_t e0 = 0; e0 < kIirChunk; e0 += 16) {
                             double a[16];
@@ -315,12 +323,20 @@ __global__ __launch_bounds__(kIirThreads) void k_iir_pipe(uint8_t* __restrict__ 
 #pragma unroll
                             for (uint32_t e = 0; e < 16; ++e) a[e] = L.ff[bi][e0 + e][lane];
 #pragma unroll
-                            for (uint32_t e = 0; e < 16; ++e) o[e] = one(a[e]);
+                            for (uint32_t e = 0; e < 16; ++e) o[e] = (int32_t)rec(a[e]);
+#pragma unroll
+                            for (uint32_t e = 0; e < 16; e += 2) mx = max(mx, max(o[e], o[e + 1]));  // (v_max3_i32)
 #pragma unroll
                             for (uint32_t e = 0; e < 16; ++e) L.out[bi][e0 + e][lane] = o[e];
                         }
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(mx == 0x7FFFFFFF) != 0ull, 0)) {
+#pragma unroll
+                            for (int i = 0; i < NC; ++i) f.y[i] = ysave[i];
+#pragma unroll 1
+                            for (uint32_t e = 0; e < kIirChunk; ++e) L.out[bi][e][lane] = trunc_i32_c(rec(L.ff[bi][e][lane]));
+                        }
                     } else {
-                        for (uint32_t e = 0; e < cnt; ++e) L.out[bi][e][lane] = one(L.ff[bi][e][lane]);
+                        for (uint32_t e = 0; e < cnt; ++e) L.out[bi][e][lane] = trunc_i32_c(rec(L.ff[bi][e][lane]));  // C truncation (rspt_test.cpp:130)
                     }
                     if (SHARED && t == nchunks) {  // the x ring the next channel's initialisation starts from (its first NC - 1 calls see it)
 #pragma unroll
