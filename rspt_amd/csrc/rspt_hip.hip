@@ -653,8 +653,13 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
         return RSPT_HIP_ERR_ALLOC;
     }
     {
-        static CrcConsts cc;  // ~87 KB: keep it off the stack
-        make_crc_consts(cc);
+        // ~87 KB of constants, computed once per process (a function-local static: packers are created from several host
+        // threads at once -- one per device, tests/cxx/shard_devices.cpp -- and the initialisation of such a static is thread-safe)
+        static const CrcConsts& cc = *[] {
+            CrcConsts* c = new CrcConsts;
+            make_crc_consts(*c);
+            return c;
+        }();
         if (hipMalloc(&p->crc, sizeof(CrcConsts)) != hipSuccess || hipMalloc(&p->nb_state, 4 * sizeof(uint32_t)) != hipSuccess) {
             rspt_hip_packer_destroy(p);
             return RSPT_HIP_ERR_ALLOC;

@@ -3,7 +3,7 @@ sizes -- every produced stream against the CPU oracle (oracle/: the restatement 
 the input (lossless packers) or the oracle's decode (lossy ones).  Not a test (it runs as long as it is told to); a mismatch prints
 the seed of the case, which reproduces it.
 
-    python tools/soak.py [seconds, default 300] [first seed, default 1]
+    python tools/soak.py [seconds, default 300] [first seed, default 1] [host threads, default 1]
 """
 import os
 import sys
@@ -21,7 +21,30 @@ from test_gpu_fuzz import KINDS as BYTE_KINDS, _gen as gen_bytes
 from oracle.oracle import Oracle
 from rspt_amd import api
 
-orc = Oracle()
+class Locked:
+    """the CPU oracle behind one lock (threaded runs: the checker is not what is being tested for thread safety)"""
+
+    def __init__(self, obj, lock):
+        object.__setattr__(self, "_o", obj)
+        object.__setattr__(self, "_k", lock)
+
+    def __getattr__(self, name):
+        v = getattr(self._o, name)
+        if not callable(v):
+            return v
+
+        def call(*a, **kw):
+            a = [x._o if isinstance(x, Locked) else x for x in a]
+            with self._k:
+                r = v(*a, **kw)
+            return Locked(r, self._k) if type(r).__name__ == "Packer" else r
+
+        return call
+
+
+import threading
+
+orc = Locked(Oracle(), threading.RLock())
 
 
 def pick_shape(r, kind):
@@ -270,6 +293,30 @@ def one_case(seed, keep=None):
                 pk3.close()
                 po3.close()
             pk2.close()
+            # ... and into a destination too short for some of the streams: those report the size they need (bit 63), the others arrive,
+            # nothing lands behind the destination
+            if r.integers(0, 4) == 0:
+                pk4, po4 = api.SignalPacker(kind, bps, nch, ns, nb0), orc.packer(kind, bps, nch, ns, nb0)
+                if be:
+                    pk4.set_byte_order(big_endian=True)
+                want4 = [po4.compress(b_) for b_ in blocks]
+                short = max(64, int(r.integers(16, max(len(w_) for w_ in want4) + 64)) // 16 * 16)
+                flat = torch.full((B * short + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+                sz4 = torch.zeros(B, dtype=torch.int64, device="cuda")
+                pk4.compress_batch(d_src, flat[: B * short].view(B, short), sz4, short)
+                torch.cuda.synchronize()
+                h4, s4 = flat.cpu().numpy(), sz4.cpu().numpy()
+                if (h4[B * short :] != 0xA5).any():
+                    bad.append("call %d: short destination (stride %d): bytes written behind it" % (call, short))
+                for i in range(B):
+                    need = int(s4[i]) & ((1 << 63) - 1)
+                    if len(want4[i]) <= short:
+                        if int(s4[i]) != len(want4[i]) or h4[i * short : i * short + need].tobytes() != want4[i]:
+                            bad.append("call %d block %d: short destination (stride %d): fitting stream differs (size word %d, want %d)" % (call, i, short, int(s4[i]), len(want4[i])))
+                    elif int(s4[i]) >= 0 or need != len(want4[i]):
+                        bad.append("call %d block %d: short destination (stride %d): size word %d for a stream of %d bytes" % (call, i, short, int(s4[i]), len(want4[i])))
+                pk4.close()
+                po4.close()
             for i in range(B):
                 # the batch is decoded with the nb the handle ended on: streams written before an escalation inside this batch have
                 # fewer planes and cannot be decoded by this handle any more (nor by the reference's object)
@@ -315,6 +362,40 @@ def one_case(seed, keep=None):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    nthreads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if nthreads > 1:
+        # several host threads, each with its own handles and cases (the library's promise: one packer per thread at a time --
+        # creation, compression and destruction of different packers may overlap freely)
+        tot = [0, 0, 0]
+        lock = threading.Lock()
+
+        def worker(w):
+            t0, seed = time.time(), seed0 + 1000000 * w
+            while time.time() - t0 < budget:
+                res, desc = one_case(seed)
+                with lock:
+                    if res is not None:
+                        tot[0] += 1
+                        tot[1] += res[0]
+                        if res[1]:
+                            tot[2] += 1
+                            print("MISMATCH (thread %d) %s" % (w, desc))
+                            for b in res[1][:6]:
+                                print("    " + b)
+                            sys.stdout.flush()
+                seed += 1
+
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(nthreads)]
+        for t in ths:
+            t.start()
+        while any(t.is_alive() for t in ths):
+            time.sleep(45)
+            print("... %d cases (%d blocks), %d bad" % tuple(tot), flush=True)
+        for t in ths:
+            t.join()
+        print("soak: %d threads from seed %d (+1000000 per thread), %d cases, %d blocks compared with the oracle, %d cases with a mismatch, %.0f s"
+              % (nthreads, seed0, tot[0], tot[1], tot[2], budget))
+        sys.exit(1 if tot[2] else 0)
     t0 = time.time()
     seed = seed0
     ncases = nblocks = nbad = nrefused = 0
