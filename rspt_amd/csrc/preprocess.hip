@@ -757,10 +757,23 @@ __global__ __launch_bounds__(256) void k_tile_stream(const uint8_t* __restrict__
 // planar int32 [nch][ns] (the output of a transform kernel) -> planes, with the
 // optional flat xdelta stage (dct: signal_packer_dct.cpp:117-119; hadamard: none).
 // Element i only needs p[i-1], p[i-2]: no transposition, one thread per 16 elements.
+// needmask (optional; the wide-block front end of the xdelta packer): the magnitudes of the values, folded to the three
+// thresholds that decide the number of planes (need_from_mask)
 template <bool XDELTA>
 __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict__ planar, Geom g, uint32_t nplanes,
-                                                       uint8_t* __restrict__ planes, uint32_t* __restrict__ nzflag) {
+                                                       uint8_t* __restrict__ planes, uint32_t* __restrict__ nzflag, uint32_t* __restrict__ needmask) {
     const uint32_t b = blockIdx.y;
+    // (sign-extended from the sample width first: what lies above it never reaches the decoded samples; transform_item does the same)
+    const uint32_t sx = 32u - 8u * g.bps;
+    auto magnitude = [&](uint32_t v) -> uint32_t {
+        const int32_t x = (int32_t)(v << sx) >> sx;
+        return (uint32_t)(x ^ (x >> 31));
+    };
+    auto publish_mag = [&](uint32_t mag) {
+        mag = wave_or_u32(mag);
+        const uint32_t f = (mag >= 0x80u ? 0x80u : 0u) | (mag >= 0x8000u ? 0x8000u : 0u) | (mag >= 0x800000u ? 0x800000u : 0u);
+        if (f && lane_id() == (uint32_t)__builtin_ctzll(__ballot(1))) atomicOr(&needmask[b], f);
+    };
     {
         // Fully coalesced form.  A wave takes 1024 consecutive elements (one KiB of every plane); in each of four rounds
         // lane l loads elements [256 q + 4 l, +4) as 16 bytes and stores one dword per plane.  XDELTA: element i needs
@@ -779,6 +792,7 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
                 front2 = (uint32_t)pw_[wbase - 2];
             }
             uint32_t nzk[4] = {0, 0, 0, 0};
+            uint32_t mag = 0;
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
                 uint32_t a0 = v[q].x, a1 = v[q].y, a2 = v[q].z, a3 = v[q].w;
@@ -796,6 +810,8 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
                     a2 = o2 ^ o1;
                     a3 = o3 ^ o2;
                 }
+                if (needmask)
+                    mag |= magnitude(a0) | magnitude(a1) | magnitude(a2) | magnitude(a3);
                 const uint32_t lo01 = __builtin_amdgcn_perm(a1, a0, 0x05010400u), hi01 = __builtin_amdgcn_perm(a1, a0, 0x07030602u);
                 const uint32_t lo23 = __builtin_amdgcn_perm(a3, a2, 0x05010400u), hi23 = __builtin_amdgcn_perm(a3, a2, 0x07030602u);
                 const uint32_t pl[4] = {__builtin_amdgcn_perm(lo23, lo01, 0x05040100u), __builtin_amdgcn_perm(lo23, lo01, 0x07060302u),
@@ -811,21 +827,25 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
             for (uint32_t k = 0; k < nplanes; ++k) {
                 if (__ballot(nzk[k] != 0) && l == 0) atomicOr(&nzflag[hb_index(g, b, k, wbase >> 16)], 1u << ((wbase >> 12) & 15u));
             }
+            if (needmask) publish_mag(mag);
             return;
         }
     }
     const uint32_t i0 = (blockIdx.x * 256 + threadIdx.x) * 16;
-    if (i0 >= g.N) return;  // (a wave's 1024 elements never straddle a 64 KiB hzr block)
+    // (a wave's 1024 elements never straddle a 64 KiB hzr block.)  Lanes past the block's end stay in the wave with nothing to do
+    // -- the magnitude reduction at the end is a cross-lane one, and lanes that have left would hand it stale registers
+    if (!__ballot(i0 < g.N)) return;
     const int32_t* p = planar + (size_t)b * g.N;
-    const uint32_t cnt = min(16u, g.N - i0);
+    const uint32_t cnt = i0 < g.N ? min(16u, g.N - i0) : 0u;
     uint32_t p1 = 0, oprev = 0;
-    if (XDELTA && i0 >= 1) {
+    if (XDELTA && i0 >= 1 && cnt) {
         p1 = (uint32_t)p[i0 - 1];
         uint32_t p2 = i0 >= 2 ? (uint32_t)p[i0 - 2] : 0u;
         oprev = p1 - p2 - 128u;
     }
     uint32_t pw[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     uint32_t xs[16];
+    uint32_t mag = 0;
     if (cnt == 16 && (reinterpret_cast<uintptr_t>(p + i0) & 15u) == 0) {  // four 16-byte loads instead of sixteen dword loads at a 64-byte lane stride
         const uint4* p4 = reinterpret_cast<const uint4*>(p + i0);
 #pragma unroll
@@ -851,6 +871,7 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
                 oprev = o;
                 p1 = x;
             }
+            mag |= magnitude(v);
             const uint32_t sh = (e & 3) * 8;
             pw[0][e >> 2] |= (v & 0xFFu) << sh;
             pw[1][e >> 2] |= ((v >> 8) & 0xFFu) << sh;
@@ -869,6 +890,7 @@ __global__ __launch_bounds__(256) void k_planar_planes(const int32_t* __restrict
             for (uint32_t i = 0; i < cnt; ++i) dp[i] = (uint8_t)(pw[k][i >> 2] >> ((i & 3) * 8));
         }
     }
+    if (needmask) publish_mag(mag);
 }
 
 // interleaved native -> planar int32 [nch][ns] (front end of the transform packers)
@@ -897,6 +919,30 @@ __global__ __launch_bounds__(256) void k_tile_planar(const uint8_t* __restrict__
         planar[(size_t)b * g.N + (size_t)c * g.ns + s0 + t] = sample_from_bytes<BPS>(tile + ((size_t)t * g.nch + c) * BPS, aligned4, g.be != 0);
     }
 }
+
+// The same for blocks too WIDE for that (a 16-sample tile of all channels no longer fits the LDS: more than ~1000 channels): a
+// plain 64 x 64 transpose per workgroup, any sample width and byte order.  The front end of every packer for such shapes -- the
+// xdelta / hzr packers go on with k_planar_planes over the planar block (rspt_hip.hip: wide); a fallback, not a fast path.
+template <int BPS>
+__global__ __launch_bounds__(256) void k_wide_planar(const uint8_t* __restrict__ src, Geom g, int32_t* __restrict__ planar) {
+    __shared__ int32_t tile[64][65];
+    const uint32_t tid = threadIdx.x, b = blockIdx.z;
+    const uint32_t s0 = blockIdx.x * 64u, c0 = blockIdx.y * 64u;
+    const uint8_t* blk = src + (size_t)b * g.block_bytes;
+    for (uint32_t q = tid; q < 4096u; q += 256u) {
+        const uint32_t t = q >> 6, c = q & 63u;  // consecutive lanes: consecutive channels of one sample row
+        if (s0 + t < g.ns && c0 + c < g.nch) tile[c][t] = sample_from_bytes<BPS>(blk + ((size_t)(s0 + t) * g.nch + c0 + c) * BPS, false, g.be != 0);
+    }
+    __syncthreads();
+    for (uint32_t q = tid; q < 4096u; q += 256u) {
+        const uint32_t c = q >> 6, t = q & 63u;  // consecutive lanes: consecutive samples of one channel
+        if (s0 + t < g.ns && c0 + c < g.nch) planar[(size_t)b * g.N + (size_t)(c0 + c) * g.ns + s0 + t] = tile[c][t];
+    }
+}
+template __global__ void k_wide_planar<1>(const uint8_t*, Geom, int32_t*);
+template __global__ void k_wide_planar<2>(const uint8_t*, Geom, int32_t*);
+template __global__ void k_wide_planar<3>(const uint8_t*, Geom, int32_t*);
+template __global__ void k_wide_planar<4>(const uint8_t*, Geom, int32_t*);
 
 // The common shape of the same conversion -- int32 samples, nch % 4 == 0, ns % 4 == 0, 16-byte aligned input -- with 16-byte
 // global accesses on both sides and no division per element (the mirror image of decode.hip: k_planar_native_i32x4).
@@ -995,7 +1041,7 @@ template __global__ void k_tile_stream<4, false, false>(const uint8_t*, Geom, ui
 template __global__ void k_tile_stream<2, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_tile_stream<3, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
 template __global__ void k_tile_stream<4, false, true>(const uint8_t*, Geom, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, const uint32_t*, uint32_t);
-template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
-template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*);
+template __global__ void k_planar_planes<true>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*, uint32_t*);
+template __global__ void k_planar_planes<false>(const int32_t*, Geom, uint32_t, uint8_t*, uint32_t*, uint32_t*);
 
 }  // namespace rspt

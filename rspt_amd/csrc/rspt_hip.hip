@@ -208,6 +208,7 @@ struct rspt_hip_packer {
     uint32_t Tp[5] = {0, 0, 0, 0, 0};  // k_tile_planes: tile length when kcount planes are staged: rows [kcount*nch][Tp+16] + nz flags
 
     unsigned long long* stamps = nullptr;  // diagnostic s_memtime stamps: [512 hzr blocks][16 waves][8]
+    bool wide = false;          // more channels than a 16-sample tile of the front-end kernels holds in LDS: k_wide_planar + k_planar_planes
     uint32_t k1_threads = 256;  // workgroup size of k_tile_planes (RSPT_K1_THREADS)
     uint32_t k1_grid = 0;       // workgroups of k_tile_planes; 0 = by LDS footprint (RSPT_K1_GRID, tuning knob)
     uint32_t hist_grid = 0;     // workgroups of the persistent k_hist / k_encode; 0 = two per CU (a CU's wave slots: one batch at a time)
@@ -277,6 +278,21 @@ static void launch_planes(rspt_hip_packer* p, const uint8_t* d_src, size_t nbloc
 template <int BPS>
 static uint32_t launch_front(rspt_hip_packer* p, const uint8_t* d_src, size_t nblocks, hipStream_t st) {
     const Geom& g = p->g;
+    if (p->wide) {
+        // wide blocks (> ~1000 channels): transpose to the planar block, then -- for the two hzr packers -- the flat stage over it.
+        // All four planes are written (an escalation inside the batch needs no second pass), nbuse[] says how many the encoders take.
+        hipLaunchKernelGGL(k_wide_planar<BPS>, dim3((g.ns + 63) / 64, (g.nch + 63) / 64, (unsigned)nblocks), dim3(256), 0, st, d_src, g, p->planar);
+        if (g.kind == RSPT_HIP_KIND_XDELTA_HZR || g.kind == RSPT_HIP_KIND_HZR) {
+            const bool xd = g.kind == RSPT_HIP_KIND_XDELTA_HZR;
+            const dim3 pg((g.N + 4095) / 4096, (unsigned)nblocks);
+            if (xd)
+                hipLaunchKernelGGL((k_planar_planes<true>), pg, dim3(256), 0, st, p->planar, g, 4u, p->planes, p->nzflag, p->needmask);
+            else
+                hipLaunchKernelGGL((k_planar_planes<false>), pg, dim3(256), 0, st, p->planar, g, 4u, p->planes, p->nzflag, (uint32_t*)nullptr);
+            hipLaunchKernelGGL(k_nb_scan, dim3(1), dim3(1024), 0, st, p->needmask, (uint32_t)nblocks, p->nb_state, p->nbuse, xd ? 1 : 0);
+        }
+        return 4;
+    }
     if (g.kind == RSPT_HIP_KIND_XDELTA_HZR) {
         const uint32_t np = p->nb_host;
         launch_planes<BPS, true>(p, d_src, nblocks, 0, np, nullptr, st);
@@ -557,9 +573,9 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
         // k_tile_planar stages the contiguous input tile (T*nch*bps + 32 bytes) in LDS
         uint64_t t = (64 * 1024 - 32) / rowb;
         t &= ~15ull;
-        if (t < 16) {
-            delete p;
-            return RSPT_HIP_ERR_UNSUPPORTED;
+        if (t < 16) {  // a 16-sample tile of all channels does not fit: the wide-block front end (k_wide_planar), any packer
+            p->wide = true;
+            t = 16;
         }
         p->T = (uint32_t)(t > 4096 ? 4096 : t);
         if (p->T > ns16) p->T = ns16;
@@ -581,9 +597,9 @@ int rspt_hip_packer_create(rspt_hip_packer** out, int kind_and_flags, size_t bps
 #ifdef RSPT_DIAG
             if (const char* e = getenv("RSPT_TILE")) Tp = (uint32_t)atoi(e) & ~15u;  // tuning knob (diagnostic builds only)
 #endif
-            if (Tp < 16) {
-                delete p;
-                return RSPT_HIP_ERR_UNSUPPORTED;
+            if (Tp < 16) {  // the plane rows of a 16-sample tile do not fit either way (about a thousand channels and up)
+                p->wide = true;
+                Tp = 16;
             }
             if (Tp > ns16) Tp = ns16;
             p->Tp[kc] = Tp;
@@ -919,14 +935,14 @@ static int phase_front(rspt_hip_packer* p, const uint8_t* src, size_t nblocks, h
         if (g.ns > 65536u) {  // two passes over the planar row (any 2^k the reference's own transform takes, fwht.c:4-28)
             hipLaunchKernelGGL(k_row_means, dim3(g.nch, B), dim3(1024), 0, st, p->planar, g, p->means, p->mean_i32);
             launch_fwht_big<true>(p, B, st);
-            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
+            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag, (uint32_t*)nullptr);
         } else if (g.ns == 65536u) {  // the whole row in registers: read once, and the byte planes written straight from them
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht64k<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
             hipLaunchKernelGGL((k_fwht64k<true, true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means, p->planes, p->nzflag, 3u);
         } else {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fwht<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fw_lds);
             hipLaunchKernelGGL((k_fwht<true>), dim3(g.nch, B), dim3(1024), fw_lds, st, p->planar, g, p->means);
-            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag);
+            hipLaunchKernelGGL((k_planar_planes<false>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar, g, 3u, p->planes, p->nzflag, (uint32_t*)nullptr);
         }
     } else if (g.kind == RSPT_HIP_KIND_DCT) {
         if (p->dct_fft) {
@@ -939,7 +955,7 @@ static int phase_front(rspt_hip_packer* p, const uint8_t* src, size_t nblocks, h
             hipLaunchKernelGGL((k_dct<true>), dim3((g.ns + 255) / 256, (g.nch + kDctCh - 1) / kDctCh, B), dim3(256), 0, st, p->planar, g, p->means,
                                p->cos_tab, p->dct_scale0, p->dct_scale1, p->dct_cs0, p->planar2);
         }
-        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes, p->nzflag);
+        hipLaunchKernelGGL((k_planar_planes<true>), dim3((g.N + 4095) / 4096, B), dim3(256), 0, st, p->planar2, g, 2u, p->planes, p->nzflag, (uint32_t*)nullptr);
     }
     HIPCHK(p, hipGetLastError());
 

@@ -472,3 +472,37 @@ def test_baseline_config5_scale(api, orc, nblocks, first):
     torch.cuda.synchronize()
     assert torch.equal(out, d_src) and torch.equal(used, d_sizes)
     pk.close()
+
+
+@pytest.mark.parametrize("kind,bps,nch,ns", [("xdelta_hzr", 4, 1100, 70), ("xdelta_hzr", 2, 3000, 33), ("xdelta_hzr", 3, 1302, 80), ("hzr", 1, 1236, 105),
+                                              ("hzr", 4, 1024, 64), ("hadamard", 4, 1500, 64), ("dct", 2, 2100, 48), ("xdelta_hzr", 4, 8000, 9)])
+def test_blocks_wider_than_a_front_end_tile(api, orc, kind, bps, nch, ns):
+    """More channels than a 16-sample tile of the front-end kernels holds in LDS (about a thousand and up; the reference takes
+    any count): the wide-block front end -- a 64 x 64 transpose to the planar block (k_wide_planar), then the flat stage over it
+    -- gives the oracle's streams, escalation inside the batch included, and the decoder gives the blocks back."""
+    import torch
+
+    po = orc.packer(kind, bps, nch, ns, 1)
+    pk = api.SignalPacker(kind, bps, nch, ns, 1)
+    lim = 1 << (8 * bps - 1)
+    for call in range(2):
+        amps = [3, min(lim - 1, 1 << 14), min(lim - 1, 1 << 29)] if call == 0 else [min(lim - 1, 1 << 29), 60]
+        blocks = [cases._rand_native(nch, ns, bps, 8800 + 10 * call + i, a, walk=bool(i & 1)) for i, a in enumerate(amps)]
+        want = [po.compress(b) for b in blocks]
+        ref_dec = None
+        d_src = torch.from_numpy(np.stack(blocks)).cuda()
+        d_dst, d_sizes = pk.compress_batch(d_src)
+        torch.cuda.synchronize()
+        for i, w in enumerate(want):
+            got = d_dst[i, : int(d_sizes[i])].cpu().numpy().tobytes()
+            assert got == w, "call %d block %d: %s" % (call, i, describe_mismatch(got, w, 3 * nch if kind in ("dct", "hadamard") else 0))
+        if kind == "xdelta_hzr":
+            assert pk.nb == orc.packer_nb(po)
+        # the last stream through the host-pointer calls, and back
+        one = pk.compress(blocks[-1])
+        assert one == po.compress(blocks[-1])
+        dec, used = pk.decompress(one)
+        assert used == len(one) and dec == po.decompress(one)[0]
+        if kind == "xdelta_hzr":
+            assert dec == blocks[-1].tobytes()
+    pk.close()

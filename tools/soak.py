@@ -58,8 +58,8 @@ def pick_shape(r, kind):
     style = int(r.integers(0, 5))
     if r.integers(0, 40) == 0:  # now and then the BASELINE shapes at full size
         return (64, 65536) if r.integers(0, 2) else (12, 34199)
-    if r.integers(0, 30) == 0:  # very wide / very long
-        return (int(r.integers(300, 1500)), int(r.integers(1, 200))) if r.integers(0, 2) else (int(r.integers(1, 3)), int(r.integers(300000, 2200000)))
+    if r.integers(0, int(os.environ.get("SOAK_WIDE_ONE_IN", "30"))) == 0:  # very wide / very long
+        return (int(r.integers(300, 6000)), int(r.integers(1, 200))) if r.integers(0, 2) else (int(r.integers(1, 3)), int(r.integers(300000, 2200000)))
     if style == 0:  # many channels, short
         return int(r.integers(33, 200)), int(r.integers(1, 600))
     if style == 1:  # few channels, long, ragged
