@@ -234,7 +234,12 @@ def one_case(seed, keep=None):
     lim = 1 << (8 * bps - 1)
     for call in range(calls):
         B = int(r.integers(1, 5)) if nch * ns < (1 << 20) else 1
+        if nch * ns <= 20000 and r.integers(0, 8) == 0:
+            B = int(r.integers(5, 300))  # many small blocks in one launch: the work queues, k_layout, the container index
         amps = [int(min(lim - 1, r.choice([1, 3, 60, 1 << 7, 1 << 10, 1 << 14, 1 << 21, 1 << 29]))) for _ in range(B)]
+        if B > 4:  # (mostly small amplitudes, a step somewhere: one escalation inside the batch, not one per block)
+            step = int(r.integers(0, B + 1))
+            amps = [min(a_, 60) if i < step else a_ for i, a_ in enumerate(amps)]
         blocks = [cases._rand_native(nch, ns, bps, int(r.integers(1 << 30)), max(1, a), walk=bool(r.integers(2))) for a in amps]
         if r.integers(0, 6) == 0:
             blocks[0] = np.zeros_like(blocks[0])  # an all-zero block now and then
