@@ -203,6 +203,67 @@ def feed_case(seed, r):
     return (n, bad), desc
 
 
+def foreign_case(seed, r):
+    """Valid streams that neither encoder would write: some hzr blocks of the oracle's stream re-encoded as PlainCopy (raw bytes,
+    mode 0) -- a decoder has to take any valid stream, whatever mode decisions its writer made (hzr_decode.c:335-567).  int8 samples
+    through the hzr packer: plane 0 is the data, planes 1-3 its sign extension.  The oracle's decoder checks the crafted stream first."""
+    import struct
+
+    total = int(r.integers(1, 400000))
+    pieces = []
+    while sum(q.size for q in pieces) < total:
+        k = str(r.choice(BYTE_KINDS + ["zeros"]))
+        ln = int(r.choice([300, 4096, 5000, 40000, 65536, 70000, 150000]))
+        if ln < 1000 and k not in ("zeros", "dense", "noise", "const", "peaky"):
+            k = "dense"
+        pieces.append(np.zeros(ln, dtype=np.uint8) if k == "zeros" else gen_bytes(int(r.integers(1 << 30)), ln, k))
+    data = np.concatenate(pieces)[:total]
+    n = data.size
+    desc = "seed %d: foreign stream, bytes n %d" % (seed, n)
+    po = orc.packer("hzr", 1, 1, n)
+    s0 = po.compress(data)
+    neg = (data.view(np.int8) < 0)
+    raw = [data, np.where(neg, 0xFF, 0).astype(np.uint8)]  # plane 0, planes 1..3
+    ps = parse_stream(s0)
+    out = bytearray(s0[:1])
+    changed = 0
+    for k, pl in enumerate(ps["planes"]):
+        body = bytearray(struct.pack("<I", pl["in_size"]))
+        for j, (mode, plen, crc, off) in enumerate(pl["blocks"]):
+            lo = j * 65536
+            rb_ = raw[min(k, 1)][lo : lo + 65536].tobytes()
+            if mode != 0 and r.integers(0, 3) == 0:
+                body += struct.pack("<HIB", len(rb_) - 1, orc.crc32c(rb_), 0) + rb_
+                changed += 1
+            else:
+                body += s0[off : off + 7 + plen]
+        out += struct.pack("<I", len(body)) + body
+    crafted = bytes(out)
+    bad = []
+    ref, used_ref, rc = po.decompress(crafted)
+    if ref != data.tobytes() or used_ref != len(crafted):
+        return None, desc + " (the crafted stream does not pass the oracle's decoder: rc %d, consumed %d of %d)" % (rc, used_ref, len(crafted))
+    pk = api.new_hzr(1, 1, n)
+    try:
+        dec, used = pk.decompress(crafted)
+        if used != len(crafted) or dec != data.tobytes():
+            bad.append("%d of the blocks re-encoded as PlainCopy: decode differs (consumed %d of %d)" % (changed, used, len(crafted)))
+    except api.RsptHipError as e:
+        bad.append("%d of the blocks re-encoded as PlainCopy: %s" % (changed, e))
+    # ... and in a batch beside the stream as written
+    stride = (max(len(crafted), len(s0)) + 255) // 256 * 256
+    st = np.zeros((2, stride), dtype=np.uint8)
+    st[0, : len(crafted)] = np.frombuffer(crafted, dtype=np.uint8)
+    st[1, : len(s0)] = np.frombuffer(s0, dtype=np.uint8)
+    d_out, d_used = pk.decompress_batch(torch.from_numpy(st).cuda(), 2, stride)
+    torch.cuda.synchronize()
+    if d_used.cpu().tolist() != [len(crafted), len(s0)] or d_out[0].cpu().numpy().tobytes() != data.tobytes() or d_out[1].cpu().numpy().tobytes() != data.tobytes():
+        bad.append("batch decode of the crafted stream beside the original differs (consumed %s)" % d_used.cpu().tolist())
+    pk.close()
+    po.close()
+    return (2, bad), desc
+
+
 THREADED = [False]
 
 
@@ -252,6 +313,8 @@ def one_case(seed, keep=None):
         return feed_case(seed, rb)
     if keep is None and rb.integers(0, 12) == 0 and not THREADED[0]:  # (its checker reaches into the oracle past the lock)
         return fft_case(seed, rb)
+    if keep is None and rb.integers(0, 10) == 0:
+        return foreign_case(seed, rb)
     if kind == "iir":
         return iir_case(seed, r)
     bps = int(r.choice([4, 4, 3, 2, 1]))
