@@ -359,9 +359,23 @@ def one_case(seed, keep=None):
             keep.append(dict(kind=kind, bps=bps, nch=nch, ns=ns, nb0=nb0, be=be, feed=feed, want=want))
         if r.integers(0, 2) == 0 or B == 1:  # the host-pointer entry point, block by block
             got, dec = [], []
+            pinned = r.integers(0, 3) == 0  # page-locked buffers: read and written in place across the link, at odd offsets now and then
+            if pinned:
+                off = int(r.choice([0, 0, 16, 4, 1]))
+                hsrc, hdst, hback = api.HostBuffer(pk.block_bytes + 64), api.HostBuffer(2 * pk.block_bytes + 8192), api.HostBuffer(pk.block_bytes + 64)
             for f in feed:  # (decoded at once: a stream carries no nb, the handle decodes with the nb it has reached -- like the reference's object)
-                got.append(pk.compress(f))
-                dec.append(pk.decompress(got[-1])[0])
+                if pinned:
+                    hsrc.a[off : off + f.size] = f
+                    n_ = pk.compress_into(hsrc.a[off : off + f.size], hdst.a[off:])
+                    got.append(hdst.a[off : off + n_].tobytes())
+                    used_ = pk.decompress_into(hdst.a[off : off + n_], hback.a[off : off + f.size])
+                    dec.append(hback.a[off : off + f.size].tobytes() if used_ == n_ else b"")
+                else:
+                    got.append(pk.compress(f))
+                    dec.append(pk.decompress(got[-1])[0])
+            if pinned:
+                for hb_ in (hsrc, hdst, hback):
+                    hb_.close()
         else:  # one device-resident batch
             d_src = torch.from_numpy(np.stack(feed)).cuda()
             d_dst, d_sizes = pk.compress_batch(d_src)
