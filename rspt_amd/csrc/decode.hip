@@ -116,7 +116,7 @@ __global__ void k_dec_frame(const uint8_t* __restrict__ src, uint64_t src_stride
         atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
     }
     if (k == nb - 1 && !bad) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)(pos + 4 + plen));
-    if (k == 0)
+    if (k == 0 && 1ull + g.hdr_len <= src_stride)  // (a stream shorter than its own header is flagged above and not read here)
         for (uint32_t i = 0; i < g.hdr_len; ++i) means[(size_t)b * g.hdr_len + i] = s[1 + i];  // base.cpp:111-115
 }
 

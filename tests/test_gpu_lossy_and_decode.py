@@ -374,3 +374,20 @@ def test_dct_decode_where_the_truncation_overflows(api, orc, bps, nch, ns, amp):
         dec, used = pk.decompress(got)
         assert used == len(got) and dec == ref
         pk.close()
+
+
+@pytest.mark.gpu
+def test_streams_shorter_than_their_own_header_are_flagged(api):
+    """decompress_batch over buffers whose stride is smaller than the dct packer's means header (1 + 3 nch bytes): every stream is
+    flagged, nothing is read past a stream's end (the last one ends with the allocation)."""
+    import torch
+
+    nch, ns = 700, 16
+    pk = api.SignalPacker("dct", 4, nch, ns)
+    stride = 64  # < 1 + 3 * 700
+    B = 4
+    d = torch.zeros((B, stride), dtype=torch.uint8, device="cuda")
+    d_out, d_used = pk.decompress_batch(d, B, stride)
+    torch.cuda.synchronize()
+    assert all(int(u) < 0 for u in d_used.cpu().tolist())  # bit 63: malformed
+    pk.close()
