@@ -81,6 +81,12 @@ int rspt_hip_compress(rspt_hip_packer* p, const void* src_host, void* dst_host, 
  * *src_len is an OUTPUT (bytes consumed), as in the reference. */
 int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_len, void* dst_host);
 
+/* The same for a caller that knows how many bytes are readable at src_host (no counterpart in the reference, whose decompress
+ * trusts the stream's own length fields -- as rspt_hip_decompress does, up to rspt_hip_max_compressed_size: a damaged length field
+ * of a stream from an untrusted source can send it past the end of a shorter buffer).  Nothing beyond src_host + src_cap is
+ * read; a stream whose framing says otherwise is RSPT_HIP_ERR_CORRUPT. */
+int rspt_hip_decompress_bounded(rspt_hip_packer* p, const void* src_host, size_t src_cap, size_t* src_len, void* dst_host);
+
 /* Worst-case stream size of ONE block for this packer, allowing for nb
  * escalation up to 4 (1 + header + nb*(4 + hzr_max_compressed_size(nch*ns)),
  * hzr_encode.c:489-497, signal_packer_base.cpp:83-95). */

@@ -21,7 +21,7 @@ DCT_FORCE_FFT = 0x100  # RSPT_HIP_DCT_FORCE_FFT (test hook, include/rspt_hip.h)
 # every symbol include/rspt_hip.h declares (tests check the library exports them all)
 C_ABI_SYMBOLS = [
     "rspt_hip_status_string", "rspt_hip_last_hip_error", "rspt_hip_device_count", "rspt_hip_packer_create",
-    "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_max_compressed_size",
+    "rspt_hip_packer_destroy", "rspt_hip_compress", "rspt_hip_decompress", "rspt_hip_decompress_bounded", "rspt_hip_max_compressed_size",
     "rspt_hip_block_bytes", "rspt_hip_current_nb", "rspt_hip_set_nb", "rspt_hip_set_verify", "rspt_hip_reserve", "rspt_hip_compress_batch_dev",
     "rspt_hip_decompress_batch_dev", "rspt_hip_decompress_packed_dev", "rspt_hip_pack_bound", "rspt_hip_pack_batch_dev", "rspt_hip_stream", "rspt_hip_synchronize", "rspt_hip_set_profiling", "rspt_hip_stage_count",
     "rspt_hip_stage_name", "rspt_hip_stage_times", "rspt_hip_debug_read", "rspt_hip_iir_prefilter_batch_dev", "rspt_hip_set_byte_order", "rspt_hip_host_alloc", "rspt_hip_host_free",
@@ -77,6 +77,7 @@ def lib():
     L.rspt_hip_packer_destroy.restype, L.rspt_hip_packer_destroy.argtypes = None, [C.c_void_p]
     L.rspt_hip_compress.restype, L.rspt_hip_compress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, _szp]
     L.rspt_hip_decompress.restype, L.rspt_hip_decompress.argtypes = C.c_int, [C.c_void_p, C.c_void_p, _szp, C.c_void_p]
+    L.rspt_hip_decompress_bounded.restype, L.rspt_hip_decompress_bounded.argtypes = C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, _szp, C.c_void_p]
     L.rspt_hip_compress_many.restype = C.c_int
     L.rspt_hip_compress_many.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp]
     L.rspt_hip_decompress_many.restype = C.c_int
@@ -235,11 +236,15 @@ class SignalPacker:
         self._check("rspt_hip_decompress", self._L.rspt_hip_decompress(self._h, stream.ctypes.data, C.byref(n), out.ctypes.data))
         return n.value
 
-    def decompress(self, stream):
+    def decompress(self, stream, bounded=False):
+        """bounded: rspt_hip_decompress_bounded with the length of `stream` (for streams that may be damaged)"""
         s = _as_u8(stream)
         out = np.empty(self.block_bytes, dtype=np.uint8)
         n = C.c_size_t(0)
-        self._check("rspt_hip_decompress", self._L.rspt_hip_decompress(self._h, s.ctypes.data, C.byref(n), out.ctypes.data))
+        if bounded:
+            self._check("rspt_hip_decompress_bounded", self._L.rspt_hip_decompress_bounded(self._h, s.ctypes.data, s.size, C.byref(n), out.ctypes.data))
+        else:
+            self._check("rspt_hip_decompress", self._L.rspt_hip_decompress(self._h, s.ctypes.data, C.byref(n), out.ctypes.data))
         return out.tobytes(), n.value
 
     @property

@@ -343,6 +343,18 @@ __device__ __forceinline__ void dec_block(uint32_t k, uint32_t j, uint32_t b, co
     uint8_t* out = planes + ((size_t)b * kMaxPlanes + k) * g.plane_stride + (size_t)j * kHzrBlock;  // 16-byte aligned
 
     if (mode == kModeFill) {  // hzr_decode.c:362-370
+        if (vcc) {
+            // hzr_verify checks the CRC of EVERY block (hzr_decode.c:569-624), a Fill block's one payload byte included: a flip in
+            // the fill value or in its CRC, or a mode byte turned into 2, is an error with verification on (found by the damaged-
+            // stream leg of tests/soak.py: such streams decoded to other bytes without a word).  Bytewise by one lane: L is 1 for
+            // every Fill block an encoder writes; anything longer is not worth more than being correct.
+            uint32_t c = 0xFFFFFFFFu;
+            for (uint32_t i = 0; i < L; ++i) c = vcc->table[0][(c ^ s[7 + i]) & 0xFFu] ^ (c >> 8);
+            if (~c != ld_le32(s + 2)) {  // (block-uniform: every thread computes the same)
+                if (tid == 0) atomicOr((unsigned long long*)&consumed[b], (unsigned long long)kBadBit);
+                return;
+            }
+        }
         const uint32_t v = s[7] * 0x01010101u;
         for (uint32_t i = tid; i < (out_size + 15) / 16; i += kDecThreads) reinterpret_cast<uint4*>(out)[i] = make_uint4(v, v, v, v);  // rows are padded
         return;

@@ -1764,7 +1764,8 @@ static int decompress_dev(rspt_hip_packer* p, const void* d_src, size_t src_stri
     return RSPT_HIP_OK;
 }
 
-int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_len, void* dst_host) {
+// src_cap: bytes readable at src_host (SIZE_MAX: the reference's contract -- the stream says how long it is)
+static int decompress_host(rspt_hip_packer* p, const void* src_host, size_t src_cap, size_t* src_len, void* dst_host) {
     if (!p || !src_host || !src_len || !dst_host) return RSPT_HIP_ERR_ARG;
     HIPCHK(p, hipSetDevice(p->device));
     int rc = ensure_host_staging(p);
@@ -1775,10 +1776,11 @@ int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_le
     const unsigned nb = rspt_hip_current_nb(p);
     size_t pos = 1 + p->g.hdr_len;
     for (unsigned k = 0; k < nb; ++k) {
+        if (pos > src_cap || src_cap - pos < 4) return RSPT_HIP_ERR_CORRUPT;  // (never a read past what the caller vouched for)
         uint32_t len;
         memcpy(&len, s + pos, 4);
         pos += 4 + (size_t)len;
-        if (pos > p->h_dst_cap) return RSPT_HIP_ERR_CORRUPT;
+        if (pos > p->h_dst_cap || pos > src_cap) return RSPT_HIP_ERR_CORRUPT;
     }
     HIPCHK(p, hipMemcpyAsync(p->h_dst, src_host, pos, hipMemcpyHostToDevice, p->stream));
     // a page-locked destination takes the samples straight from the inverse's last kernel (the download is that kernel's
@@ -1797,6 +1799,14 @@ int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_le
     }
     *src_len = (size_t)used;
     return RSPT_HIP_OK;
+}
+
+int rspt_hip_decompress(rspt_hip_packer* p, const void* src_host, size_t* src_len, void* dst_host) {
+    return decompress_host(p, src_host, (size_t)-1, src_len, dst_host);
+}
+
+int rspt_hip_decompress_bounded(rspt_hip_packer* p, const void* src_host, size_t src_cap, size_t* src_len, void* dst_host) {
+    return decompress_host(p, src_host, src_cap, src_len, dst_host);
 }
 
 int rspt_hip_iir_prefilter_batch_dev(rspt_hip_packer* p, void* d_buf, size_t nblocks, const double* n, const double* d, size_t nr_coefficients,

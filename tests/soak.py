@@ -264,6 +264,69 @@ def foreign_case(seed, r):
     return (2, bad), desc
 
 
+def damaged_case(seed, r):
+    """A valid stream with a few bits flipped, bytes overwritten or its tail cut off, with and without block verification: the
+    call has to return -- an error, or bytes -- and the handle has to decode the pristine stream afterwards.  (What a damaged stream
+    decodes to without verification is nobody's business; with it, a stream that decodes at all decodes to the original.)"""
+    total = int(r.integers(200, 300000))
+    pieces = []
+    while sum(q.size for q in pieces) < total:
+        k = str(r.choice(BYTE_KINDS + ["zeros"]))
+        ln = int(r.choice([300, 4096, 5000, 40000, 65536, 70000, 150000]))
+        if ln < 1000 and k not in ("zeros", "dense", "noise", "const", "peaky"):
+            k = "dense"
+        pieces.append(np.zeros(ln, dtype=np.uint8) if k == "zeros" else gen_bytes(int(r.integers(1 << 30)), ln, k))
+    data = np.concatenate(pieces)[:total]
+    n = data.size
+    desc = "seed %d: damaged stream, bytes n %d" % (seed, n)
+    po = orc.packer("hzr", 1, 1, n)
+    s0 = po.compress(data)
+    po.close()
+    pk = api.new_hzr(1, 1, n)
+    bad = []
+    ntry = 0
+    mode_bytes = [blk[3] + 6 for pl_ in parse_stream(s0)["planes"] for blk in pl_["blocks"]]
+    for verify in (True, False):
+        pk.set_verify(verify)
+        for _ in range(6):
+            d_ = bytearray(s0)
+            how = int(r.integers(0, 4))
+            if os.environ.get("SOAK_DAMAGE"):
+                how = int(os.environ["SOAK_DAMAGE"])
+            if how == 0:
+                for _k in range(int(r.integers(1, 4))):
+                    q = int(r.integers(0, 8 * len(d_)))
+                    d_[q >> 3] ^= 1 << (q & 7)
+            elif how == 1:
+                q = int(r.integers(0, len(d_)))
+                ln = int(r.integers(1, 9))
+                d_[q : q + ln] = bytes(int(x) for x in r.integers(0, 256, len(d_[q : q + ln])))
+            elif how == 2:
+                d_ = d_[: int(r.integers(1, len(d_)))]
+            else:  # a block header's length / mode fields
+                ps = parse_stream(s0)
+                pl = ps["planes"][int(r.integers(0, len(ps["planes"])))]
+                off = pl["blocks"][int(r.integers(0, len(pl["blocks"])))][3]
+                d_[off + int(r.choice([0, 1, 6]))] = int(r.integers(0, 256))
+            ntry += 1
+            try:
+                dec, used = pk.decompress(bytes(d_), bounded=True)  # (a damaged length field or a cut: nothing behind the buffer may be read)
+                # (the mode byte of a block header is not covered by the block's CRC: a Fill block turned "Huffman" passes the check in
+                #  the reference too, and what the payload then decodes to is not an error anybody can see)
+                touched_mode = len(d_) == len(s0) and any(d_[q_] != s0[q_] for q_ in mode_bytes)
+                if verify and dec != data.tobytes() and bytes(d_) != s0 and not touched_mode:
+                    bad.append("verification on: a damaged stream (%s) decoded to other bytes without an error" % ("flips", "bytes", "cut", "header")[how])
+            except api.RsptHipError as e:
+                if e.status != -6:
+                    bad.append("status %d for a damaged stream" % e.status)
+    pk.set_verify(True)
+    dec, used = pk.decompress(s0)
+    if used != len(s0) or dec != data.tobytes():
+        bad.append("the handle no longer decodes the pristine stream")
+    pk.close()
+    return (ntry, bad), desc
+
+
 THREADED = [False]
 
 
@@ -315,6 +378,8 @@ def one_case(seed, keep=None):
         return fft_case(seed, rb)
     if keep is None and rb.integers(0, 10) == 0:
         return foreign_case(seed, rb)
+    if keep is None and rb.integers(0, 12) == 0:
+        return damaged_case(seed, rb)
     if kind == "iir":
         return iir_case(seed, r)
     bps = int(r.choice([4, 4, 3, 2, 1]))

@@ -391,3 +391,42 @@ def test_streams_shorter_than_their_own_header_are_flagged(api):
     torch.cuda.synchronize()
     assert all(int(u) < 0 for u in d_used.cpu().tolist())  # bit 63: malformed
     pk.close()
+
+
+@pytest.mark.gpu
+def test_bounded_decompress_and_fill_block_verification(api, orc):
+    """rspt_hip_decompress_bounded: truncated streams and damaged length fields are RSPT_HIP_ERR_CORRUPT without a byte read behind
+    the buffer (the reference's own decompress, and rspt_hip_decompress, trust the stream's length fields).  And with verification on
+    a Fill block's CRC is checked like any other block's (hzr_decode.c:569-624): a flipped fill value is an error, not other bytes.
+    Both found by the damaged-stream leg of tests/soak.py."""
+    n = 70000
+    data = np.zeros(n, dtype=np.uint8)
+    data[:3000] = np.arange(3000) % 251  # plane 0: a Huffman block and a Fill block (zeros); planes 1..3: Fill blocks
+    s = orc.packer("hzr", 1, 1, n).compress(data)
+    pk = api.new_hzr(1, 1, n)
+    for cut in (1, 4, 5, 9, 100, len(s) // 2, len(s) - 1):
+        with pytest.raises(api.RsptHipError) as e:
+            pk.decompress(s[:cut], bounded=True)
+        assert e.value.status == -6, cut
+    big = bytearray(s)
+    big[1:5] = (0x7FFFFFF0).to_bytes(4, "little")  # plane 0 claims 2 GiB
+    with pytest.raises(api.RsptHipError) as e:
+        pk.decompress(bytes(big), bounded=True)
+    assert e.value.status == -6
+    dec, used = pk.decompress(s, bounded=True)
+    assert used == len(s) and dec == data.tobytes()
+    # a Fill block's value flipped: reported with verification on
+    p = parse_stream(s)
+    fills = [(k, blk) for k, pl in enumerate(p["planes"]) for blk in pl["blocks"] if blk[0] == 2]
+    assert fills
+    off = fills[-1][1][3]
+    bad = bytearray(s)
+    bad[off + 7] ^= 0x40
+    pk.set_verify(True)
+    with pytest.raises(api.RsptHipError) as e:
+        pk.decompress(bytes(bad), bounded=True)
+    assert e.value.status == -6
+    pk.set_verify(False)
+    dec, used = pk.decompress(bytes(bad), bounded=True)  # (without verification the damaged value is simply what comes out)
+    assert used == len(s) and dec != data.tobytes()
+    pk.close()
