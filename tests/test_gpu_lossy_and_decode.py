@@ -417,7 +417,7 @@ def test_bounded_decompress_and_fill_block_verification(api, orc):
     assert used == len(s) and dec == data.tobytes()
     # a Fill block's value flipped: reported with verification on
     p = parse_stream(s)
-    fills = [(k, blk) for k, pl in enumerate(p["planes"]) for blk in pl["blocks"] if blk[0] == 2]
+    fills = [(k, blk) for k, pl in enumerate(p["planes"]) for blk in pl["blocks"] if blk[0] == 2 and k == 0]  # (plane 0: the samples of an int8 block)
     assert fills
     off = fills[-1][1][3]
     bad = bytearray(s)
